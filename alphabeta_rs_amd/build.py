@@ -1,0 +1,55 @@
+"""Builds libabneutral_hip.so (HIP kernels + C-ABI) for gfx950 with hipcc, in-tree.
+
+-ffp-contract=off is REQUIRED: parity with the reference depends on every multiply-add staying
+unfused except the explicit __builtin_fma calls (see csrc/abn_device.hpp).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG = Path(__file__).resolve().parent
+CSRC = PKG / "csrc"
+LIB = PKG / "libabneutral_hip.so"
+SOURCES = [CSRC / "abn_api.hip"]
+DEPS = [CSRC / "abn_device.hpp", CSRC / "abn_philox.h", PKG.parent / "include" / "abneutral.h"]
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950",
+    "-O3",
+    "-std=c++17",
+    "-ffp-contract=off",
+    "-fno-fast-math",
+    "-fPIC",
+    "-shared",
+    "-Wall",
+]
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found: the ABneutral HIP library cannot be built")
+
+
+def needs_build() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in SOURCES + DEPS)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc_path(), *HIPCC_FLAGS, "-o", str(LIB), *map(str, SOURCES)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=str(PKG))
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

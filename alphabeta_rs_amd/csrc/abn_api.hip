@@ -1,0 +1,965 @@
+// C-ABI of libabneutral_hip.so (include/abneutral.h): host-side glue around the gfx950 kernels of
+// abn_device.hpp.  No CPU compute path exists here by design: if HIP is unusable every compute entry
+// point returns ABN_ERR_NO_DEVICE / ABN_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/abneutral.h"
+#include "abn_device.hpp"
+
+using namespace abn;
+
+static_assert(sizeof(abn_fit_info) == sizeof(FitInfoDev), "abn_fit_info layout");
+
+// ------------------------------------------------------------------------------------------------
+struct abn_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+};
+
+static int set_err(abn_ctx* c, int status, const std::string& msg) {
+  if (c) c->err = msg;
+  return status;
+}
+
+#define HIPCHK(ctx, call)                                                                        \
+  do {                                                                                           \
+    hipError_t e__ = (call);                                                                     \
+    if (e__ != hipSuccess)                                                                       \
+      return set_err((ctx), ABN_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e__));    \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    if (count == 0) return hipSuccess;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// pedigree topology: distinct (t0, t1-t0, t2-t0) triples, src/divergence.rs:52,57-58
+// ------------------------------------------------------------------------------------------------
+static int as_i8(double x) {  // Rust `f64 as i8`: truncate, saturate, NaN -> 0
+  if (x != x) return 0;
+  if (x >= 127.0) return 127;
+  if (x <= -128.0) return -128;
+  return (int)x;
+}
+
+struct Topology {
+  int N = 0, K = 0, T = 0, TP = 0, KP = 0, chain_stride = 0;
+  std::vector<uint32_t> tri;
+  std::vector<uint16_t> tid;
+};
+
+// rows: n rows with `stride` doubles each, generations in the first three columns
+static int build_topology(const double* rows, int n, int stride, Topology& t) {
+  if (!rows || n <= 0) return ABN_ERR_INVALID_ARG;
+  t.N = n;
+  t.tri.clear();
+  t.tid.resize((size_t)n);
+  std::unordered_map<uint32_t, uint32_t> seen;
+  int tmax = 0;
+  for (int i = 0; i < n; ++i) {
+    const int t0 = as_i8(rows[(size_t)i * stride + 0]);
+    const int t1 = as_i8(rows[(size_t)i * stride + 1]);
+    const int t2 = as_i8(rows[(size_t)i * stride + 2]);
+    // The reference inverts G for negative exponents (src/divergence.rs:17-19) and its i8 subtraction
+    // can wrap; neither is meaningful for a pedigree, so such rows are rejected.
+    if (t0 < 0 || t1 < t0 || t2 < t0) return ABN_ERR_BAD_PEDIGREE;
+    const int ea = t1 - t0, eb = t2 - t0;
+    tmax = std::max(tmax, std::max(t0, std::max(ea, eb)));
+    const uint32_t key = (uint32_t)t0 | ((uint32_t)ea << 8) | ((uint32_t)eb << 16);
+    auto it = seen.find(key);
+    uint32_t id;
+    if (it == seen.end()) {
+      id = (uint32_t)t.tri.size();
+      if (id >= 65535u) return ABN_ERR_INVALID_ARG;
+      seen.emplace(key, id);
+      t.tri.push_back(key);
+    } else {
+      id = it->second;
+    }
+    t.tid[(size_t)i] = (uint16_t)id;
+  }
+  t.K = (int)t.tri.size();
+  t.T = tmax;
+  t.TP = tmax + 1;
+  t.KP = (t.K + 1) & ~1;
+  t.chain_stride = 9 * t.TP + t.KP;
+  return ABN_OK;
+}
+
+struct DevTopology {
+  DevBuf<uint32_t> tri;
+  DevBuf<uint16_t> tid;
+};
+
+static int upload_topology(abn_ctx* c, const Topology& t, DevTopology& d) {
+  HIPCHK(c, d.tri.alloc(t.tri.size()));
+  HIPCHK(c, d.tid.alloc(t.tid.size()));
+  HIPCHK(c, hipMemcpyAsync(d.tri.p, t.tri.data(), d.tri.bytes(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d.tid.p, t.tid.data(), d.tid.bytes(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ABN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch configuration
+// ------------------------------------------------------------------------------------------------
+constexpr size_t kMaxDynLds = 64 * 1024;
+
+static int pick_lanes(int n, int requested) {
+  if (requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
+  if (n <= 32) return 8;
+  if (n <= 128) return 16;
+  if (n <= 256) return 32;
+  return 64;
+}
+static int pick_rmax(int n, int lanes) {
+  const int per = (n + lanes - 1) / lanes;
+  if (per <= 1) return 1;
+  if (per <= 2) return 2;
+  if (per <= 4) return 4;
+  if (per <= 8) return 8;
+  return 0;  // stream mode
+}
+
+template <int G>
+static hipError_t launch_fit_g(const FitArgs& a, int rmax, dim3 grid, size_t lds, hipStream_t s) {
+  switch (rmax) {
+    case 1: hipLaunchKernelGGL((abn_fit_kernel<G, 1>), grid, dim3(kWave), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((abn_fit_kernel<G, 2>), grid, dim3(kWave), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((abn_fit_kernel<G, 4>), grid, dim3(kWave), lds, s, a); break;
+    case 8: hipLaunchKernelGGL((abn_fit_kernel<G, 8>), grid, dim3(kWave), lds, s, a); break;
+    default: hipLaunchKernelGGL((abn_fit_kernel<G, 0>), grid, dim3(kWave), lds, s, a); break;
+  }
+  return hipGetLastError();
+}
+
+static int launch_fit(abn_ctx* c, const FitArgs& a, int lanes) {
+  const long long chains = (long long)a.W * a.C;
+  if (chains <= 0) return ABN_OK;
+  const int ng = kWave / lanes;
+  const size_t lds = (size_t)ng * (size_t)a.chain_stride * sizeof(double);
+  if (lds > kMaxDynLds)
+    return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS per workgroup than supported (T or K too large)");
+  const long long blocks = (chains + ng - 1) / ng;
+  if (blocks > 0x7fffffffLL) return set_err(c, ABN_ERR_INVALID_ARG, "too many chains for one launch");
+  const int rmax = pick_rmax(a.N, lanes);
+  dim3 grid((unsigned)blocks);
+  hipError_t e;
+  switch (lanes) {
+    case 8: e = launch_fit_g<8>(a, rmax, grid, lds, c->stream); break;
+    case 16: e = launch_fit_g<16>(a, rmax, grid, lds, c->stream); break;
+    case 32: e = launch_fit_g<32>(a, rmax, grid, lds, c->stream); break;
+    default: e = launch_fit_g<64>(a, rmax, grid, lds, c->stream); break;
+  }
+  HIPCHK(c, e);
+  return ABN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+extern "C" void abn_default_options(abn_options* o) {
+  if (!o) return;
+  o->seed = 20260101ull;
+  o->lanes_per_chain = 0;
+  o->strict_order = 0;
+  o->shrink_on_failed_contraction = 0;
+  o->max_iters_start = 10000;  // src/ab_neutral.rs:62
+  o->max_iters_boot = 1000;    // src/boot_model.rs:81
+  o->reserved0 = 0;
+  o->sd_tolerance = 2.220446049250313e-16;  // f64::EPSILON
+}
+
+static abn_options resolve(const abn_options* o) {
+  abn_options d;
+  abn_default_options(&d);
+  if (o) d = *o;
+  return d;
+}
+
+extern "C" int abn_version(void) { return ABN_VERSION_MAJOR * 100 + ABN_VERSION_MINOR; }
+
+extern "C" int abn_device_count(int* count) {
+  if (!count) return ABN_ERR_INVALID_ARG;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    *count = 0;
+    return ABN_ERR_NO_DEVICE;
+  }
+  *count = n;
+  return n > 0 ? ABN_OK : ABN_ERR_NO_DEVICE;
+}
+
+extern "C" int abn_init(int device_ordinal, void* stream, abn_ctx** out) {
+  if (!out) return ABN_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ABN_ERR_NO_DEVICE;
+  if (device_ordinal < 0 || device_ordinal >= n) return ABN_ERR_INVALID_ARG;
+  if (hipSetDevice(device_ordinal) != hipSuccess) return ABN_ERR_HIP;
+  abn_ctx* c = new (std::nothrow) abn_ctx();
+  if (!c) return ABN_ERR_HIP;
+  c->device = device_ordinal;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+    c->own_stream = false;
+  } else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete c;
+      return ABN_ERR_HIP;
+    }
+    c->own_stream = true;
+  }
+  *out = c;
+  return ABN_OK;
+}
+
+extern "C" int abn_shutdown(abn_ctx* c) {
+  if (!c) return ABN_ERR_INVALID_ARG;
+  if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return ABN_OK;
+}
+
+extern "C" const char* abn_last_error(const abn_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" const char* abn_status_string(int s) {
+  switch (s) {
+    case ABN_OK: return "ok";
+    case ABN_ERR_INVALID_ARG: return "invalid argument";
+    case ABN_ERR_BAD_PEDIGREE: return "bad pedigree (generation outside 0..127 or t1/t2 < t0)";
+    case ABN_ERR_NO_DEVICE: return "no HIP device";
+    case ABN_ERR_HIP: return "HIP runtime error";
+    case ABN_ERR_NO_FINITE_FIT: return "no start produced a finite fit";
+    case ABN_ERR_STATE: return "plan used out of order";
+    default: return "unknown status";
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic inputs (host side)
+// ------------------------------------------------------------------------------------------------
+// Model::new, src/structs.rs:78-96, five vertices per start (src/ab_neutral.rs:49-55)
+extern "C" int abn_gen_start_simplices(uint64_t seed, uint32_t window, int32_t n_starts, double max_divergence,
+                                       double* simplex0) {
+  if (!simplex0 || n_starts < 0) return ABN_ERR_INVALID_ARG;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  double mx = max_divergence;
+  if (!(max_divergence > 0.0)) mx = 0.1;  // :80-83
+  for (int32_t s = 0; s < n_starts; ++s)
+    for (uint32_t v = 0; v < 5; ++v) {
+      uint32_t r0[4], r1[4];
+      philox4x32_10(0u, (uint32_t)s * 5u + v, window, kTagStart, k0, k1, r0);
+      philox4x32_10(1u, (uint32_t)s * 5u + v, window, kTagStart, k0, k1, r1);
+      double* o = simplex0 + ((size_t)s * 5 + v) * 4;
+      o[0] = std::pow(10.0, uniform_from(r0[0], r0[1], -9.0, -2.0));
+      o[1] = std::pow(10.0, uniform_from(r0[2], r0[3], -9.0, -2.0));
+      o[2] = uniform_from(r1[0], r1[1], 0.0, 0.1);
+      o[3] = uniform_from(r1[2], r1[3], 0.0, mx);
+    }
+  return ABN_OK;
+}
+
+extern "C" int abn_gen_boot_simplices(uint64_t seed, uint32_t window, uint32_t b0, int64_t nb, const double params[4],
+                                      double* simplex0) {
+  if (!simplex0 || !params || nb < 0) return ABN_ERR_INVALID_ARG;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int64_t i = 0; i < nb; ++i) {
+    double* o = simplex0 + (size_t)i * 20;
+    for (int d = 0; d < 4; ++d) o[d] = params[d];
+    for (uint32_t v = 1; v < 5; ++v) {
+      uint32_t r0[4], r1[4];
+      philox4x32_10((v - 1u) * 2u + 0u, b0 + (uint32_t)i, window, kTagJitter, k0, k1, r0);
+      philox4x32_10((v - 1u) * 2u + 1u, b0 + (uint32_t)i, window, kTagJitter, k0, k1, r1);
+      o[4 * v + 0] = vary_one(params[0], r0[0], r0[1]);
+      o[4 * v + 1] = vary_one(params[1], r0[2], r0[3]);
+      o[4 * v + 2] = vary_one(params[2], r1[0], r1[1]);
+      o[4 * v + 3] = vary_one(params[3], r1[2], r1[3]);
+    }
+  }
+  return ABN_OK;
+}
+
+static int launch_gen_idx(abn_ctx* c, uint32_t* idx, int n, int b, int w, uint64_t seed, uint32_t woff, uint32_t boff) {
+  const long long total = (long long)w * b * ((n + 3) / 4);
+  if (total <= 0) return ABN_OK;
+  const long long want = (total + 255) / 256;
+  const unsigned blocks = (unsigned)std::min<long long>(want, 256LL * 32);
+  hipLaunchKernelGGL(abn_gen_idx_kernel, dim3(blocks), dim3(256), 0, c->stream, idx, n, b, w, seed, woff, boff);
+  HIPCHK(c, hipGetLastError());
+  return ABN_OK;
+}
+
+extern "C" int abn_gen_boot_indices(abn_ctx* c, uint64_t seed, uint32_t window, uint32_t b0, int64_t nb, int32_t n_rows,
+                                    uint32_t* idx) {
+  if (!c || !idx || nb < 0 || n_rows <= 0 || nb > 0x7fffffff) return ABN_ERR_INVALID_ARG;
+  if (nb == 0) return ABN_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf<uint32_t> d;
+  HIPCHK(c, d.alloc((size_t)nb * (size_t)n_rows));
+  int rc = launch_gen_idx(c, d.p, n_rows, (int)nb, 1, seed, window, b0);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(idx, d.p, d.bytes(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ABN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// (1) cost batch
+// ------------------------------------------------------------------------------------------------
+extern "C" int abn_cost_batch(abn_ctx* c, const abn_options* opts, const double* pedigree, int32_t n_rows, double p_uu0,
+                              double eqp, double eqp_weight, const double* candidates, int64_t m, const double* pred,
+                              const double* resid, const uint32_t* idx, const uint32_t* cand_to_boot,
+                              int64_t n_boot_rows, double* cost, double* dt1t2, double* p_uu_inf) {
+  if (!c) return ABN_ERR_INVALID_ARG;
+  if (!pedigree || n_rows <= 0 || !candidates || m < 0 || !cost) return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
+  if (idx && (!pred || !resid || n_boot_rows <= 0)) return set_err(c, ABN_ERR_INVALID_ARG, "bootstrap inputs");
+  if (m == 0) return ABN_OK;
+  const abn_options o = resolve(opts);
+  HIPCHK(c, hipSetDevice(c->device));
+  Topology t;
+  int rc = build_topology(pedigree, n_rows, 4, t);
+  if (rc) return set_err(c, rc, abn_status_string(rc));
+  if (idx) {
+    for (int64_t i = 0; i < m; ++i) {
+      const int64_t b = cand_to_boot ? (int64_t)cand_to_boot[i] : i;
+      if (b >= n_boot_rows) return set_err(c, ABN_ERR_INVALID_ARG, "cand_to_boot out of range");
+    }
+  }
+  DevTopology dt;
+  rc = upload_topology(c, t, dt);
+  if (rc) return rc;
+  const int N = n_rows;
+  std::vector<double> dcol((size_t)N);
+  for (int i = 0; i < N; ++i) dcol[(size_t)i] = pedigree[(size_t)i * 4 + 3];
+  DevBuf<double> dD, dpred, dresid, dcand, dcost, ddt, dpuu;
+  DevBuf<uint32_t> didx, dc2b;
+  HIPCHK(c, dD.alloc((size_t)N));
+  HIPCHK(c, dcand.alloc((size_t)m * 4));
+  HIPCHK(c, dcost.alloc((size_t)m));
+  HIPCHK(c, hipMemcpyAsync(dD.p, dcol.data(), dD.bytes(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dcand.p, candidates, dcand.bytes(), hipMemcpyHostToDevice, c->stream));
+  if (idx) {
+    HIPCHK(c, dpred.alloc((size_t)N));
+    HIPCHK(c, dresid.alloc((size_t)N));
+    HIPCHK(c, didx.alloc((size_t)n_boot_rows * (size_t)N));
+    HIPCHK(c, hipMemcpyAsync(dpred.p, pred, dpred.bytes(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dresid.p, resid, dresid.bytes(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(didx.p, idx, didx.bytes(), hipMemcpyHostToDevice, c->stream));
+    for (size_t q = 0; q < (size_t)n_boot_rows * (size_t)N; ++q)
+      if (idx[q] >= (uint32_t)N) return set_err(c, ABN_ERR_INVALID_ARG, "bootstrap index out of range");
+    if (cand_to_boot) {
+      HIPCHK(c, dc2b.alloc((size_t)m));
+      HIPCHK(c, hipMemcpyAsync(dc2b.p, cand_to_boot, dc2b.bytes(), hipMemcpyHostToDevice, c->stream));
+    }
+  }
+  if (dt1t2) HIPCHK(c, ddt.alloc((size_t)m * (size_t)N));
+  if (p_uu_inf) HIPCHK(c, dpuu.alloc((size_t)m));
+
+  const int lanes = o.strict_order ? 64 : pick_lanes(N, o.lanes_per_chain);
+  const int ng = kWave / lanes;
+  CostArgs a{};
+  a.tri = dt.tri.p;
+  a.tid = dt.tid.p;
+  a.N = N;
+  a.K = t.K;
+  a.T = t.T;
+  a.TP = t.TP;
+  a.chain_stride = t.chain_stride;
+  a.p_uu0 = p_uu0;
+  a.eqp = eqp;
+  a.eqp_w = eqp_weight;
+  a.D = dD.p;
+  a.pred = dpred.p;
+  a.resid = dresid.p;
+  a.idx = didx.p;
+  a.cand_to_boot = dc2b.p;
+  a.dmode = idx ? 1 : 0;
+  a.cand = dcand.p;
+  a.M = m;
+  a.strict = o.strict_order ? 1 : 0;
+  a.cost = dcost.p;
+  a.dt = ddt.p;
+  a.puu = dpuu.p;
+  size_t lds = ((size_t)ng * t.chain_stride + (o.strict_order ? kSelChunk : 0)) * sizeof(double);
+  if (lds > kMaxDynLds) return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS than supported");
+  const long long blocks = (m + ng - 1) / ng;
+  if (blocks > 0x7fffffffLL) return set_err(c, ABN_ERR_INVALID_ARG, "too many candidates");
+  dim3 grid((unsigned)blocks);
+  switch (lanes) {
+    case 8: hipLaunchKernelGGL(abn_cost_kernel<8>, grid, dim3(kWave), lds, c->stream, a); break;
+    case 16: hipLaunchKernelGGL(abn_cost_kernel<16>, grid, dim3(kWave), lds, c->stream, a); break;
+    case 32: hipLaunchKernelGGL(abn_cost_kernel<32>, grid, dim3(kWave), lds, c->stream, a); break;
+    default: hipLaunchKernelGGL(abn_cost_kernel<64>, grid, dim3(kWave), lds, c->stream, a); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(cost, dcost.p, dcost.bytes(), hipMemcpyDeviceToHost, c->stream));
+  if (dt1t2) HIPCHK(c, hipMemcpyAsync(dt1t2, ddt.p, ddt.bytes(), hipMemcpyDeviceToHost, c->stream));
+  if (p_uu_inf) HIPCHK(c, hipMemcpyAsync(p_uu_inf, dpuu.p, dpuu.bytes(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ABN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Nelder-Mead fit batch (explicit start simplices)
+// ------------------------------------------------------------------------------------------------
+extern "C" int abn_fit_batch(abn_ctx* c, const abn_options* opts, const double* pedigree, int32_t n_rows, double p_uu0,
+                             double eqp, double eqp_weight, const double* simplex0, int64_t f, const double* dobs_rows,
+                             int32_t max_iters, double* best, abn_fit_info* info) {
+  if (!c) return ABN_ERR_INVALID_ARG;
+  if (!pedigree || n_rows <= 0 || !simplex0 || f < 0 || !best || max_iters < 0 || f > 0x7fffffff)
+    return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
+  if (f == 0) return ABN_OK;
+  const abn_options o = resolve(opts);
+  HIPCHK(c, hipSetDevice(c->device));
+  Topology t;
+  int rc = build_topology(pedigree, n_rows, 4, t);
+  if (rc) return set_err(c, rc, abn_status_string(rc));
+  DevTopology dt;
+  rc = upload_topology(c, t, dt);
+  if (rc) return rc;
+  const int N = n_rows;
+  DevBuf<double> dD, ds0, dbest, dscal;
+  DevBuf<FitInfoDev> dinfo;
+  std::vector<double> dcol;
+  const double* dsrc = dobs_rows;
+  size_t dcount = (size_t)f * (size_t)N;
+  if (!dobs_rows) {
+    dcol.resize((size_t)N);
+    for (int i = 0; i < N; ++i) dcol[(size_t)i] = pedigree[(size_t)i * 4 + 3];
+    dsrc = dcol.data();
+    dcount = (size_t)N;
+  }
+  const double scal[3] = {p_uu0, eqp, eqp_weight};
+  HIPCHK(c, dD.alloc(dcount));
+  HIPCHK(c, ds0.alloc((size_t)f * 20));
+  HIPCHK(c, dbest.alloc((size_t)f * 4));
+  HIPCHK(c, dinfo.alloc((size_t)f));
+  HIPCHK(c, dscal.alloc(3));
+  HIPCHK(c, hipMemcpyAsync(dD.p, dsrc, dD.bytes(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(ds0.p, simplex0, ds0.bytes(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dscal.p, scal, sizeof scal, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dinfo.p, 0, dinfo.bytes(), c->stream));
+
+  FitArgs a{};
+  a.tri = dt.tri.p;
+  a.tid = dt.tid.p;
+  a.N = N;
+  a.K = t.K;
+  a.T = t.T;
+  a.TP = t.TP;
+  a.chain_stride = t.chain_stride;
+  a.p_uu = dscal.p;
+  a.eqp = dscal.p + 1;
+  a.eqp_w = dscal.p + 2;
+  a.wstride = 0;
+  a.dmode = 0;
+  a.D = dD.p;
+  a.smode = 0;
+  a.simplex0 = ds0.p;
+  a.seed = o.seed;
+  if (dobs_rows) {  // one "window" per fit: its own observed divergences
+    a.W = (int)f;
+    a.C = 1;
+  } else {
+    a.W = 1;
+    a.C = (int)f;
+  }
+  a.max_iters = max_iters;
+  a.shrink_variant = o.shrink_on_failed_contraction ? 1 : 0;
+  a.sd_tol = o.sd_tolerance;
+  a.best = dbest.p;
+  a.info = dinfo.p;
+  a.raw = nullptr;
+  const int lanes = pick_lanes(N, o.lanes_per_chain);
+  rc = launch_fit(c, a, lanes);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(best, dbest.p, dbest.bytes(), hipMemcpyDeviceToHost, c->stream));
+  if (info) HIPCHK(c, hipMemcpyAsync(info, dinfo.p, dinfo.bytes(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ABN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// (4) device-resident plan
+// ------------------------------------------------------------------------------------------------
+struct abn_plan {
+  abn_ctx* ctx = nullptr;
+  abn_options opt{};
+  Topology topo;
+  DevTopology dtopo;
+  int N = 0, W = 0, S = 0, B = 0;
+  uint32_t window_offset = 0, boot_offset = 0;
+  int lanes = 16;
+  bool windows_set = false, phase_a_done = false, ran_a = false, ran_b = false;
+  DevBuf<double> D, pred, resid, p_uu, eqp, eqp_w, simplexA, bestA, model, lse, bestB, raw_own;
+  DevBuf<FitInfoDev> infoA, infoB;
+  DevBuf<int32_t> best_start;
+  DevBuf<uint32_t> idx;
+  double* raw = nullptr;  // raw_own.p or caller-bound
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+extern "C" int abn_plan_destroy(abn_plan* p) {
+  if (!p) return ABN_ERR_INVALID_ARG;
+  for (auto& e : p->ev)
+    if (e) (void)hipEventDestroy(e);
+  delete p;
+  return ABN_OK;
+}
+
+extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double* generations, int32_t n_rows,
+                               int32_t n_windows, int32_t n_starts, int32_t n_boot, uint32_t window_offset,
+                               uint32_t boot_offset, abn_plan** out) {
+  if (!c || !out) return ABN_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (!generations || n_rows <= 0 || n_windows <= 0 || n_starts < 0 || n_boot < 0)
+    return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
+  if ((long long)n_windows * std::max(n_starts, n_boot) > 0x7fffffffLL)
+    return set_err(c, ABN_ERR_INVALID_ARG, "too many chains");
+  HIPCHK(c, hipSetDevice(c->device));
+  abn_plan* p = new (std::nothrow) abn_plan();
+  if (!p) return ABN_ERR_HIP;
+  p->ctx = c;
+  p->opt = resolve(opts);
+  p->N = n_rows;
+  p->W = n_windows;
+  p->S = n_starts;
+  p->B = n_boot;
+  p->window_offset = window_offset;
+  p->boot_offset = boot_offset;
+  int rc = build_topology(generations, n_rows, 3, p->topo);
+  if (rc) {
+    delete p;
+    return set_err(c, rc, abn_status_string(rc));
+  }
+  p->lanes = pick_lanes(n_rows, p->opt.lanes_per_chain);
+  if ((size_t)(kWave / p->lanes) * p->topo.chain_stride * sizeof(double) > kMaxDynLds ||
+      ((size_t)p->topo.chain_stride + kSelChunk) * sizeof(double) > kMaxDynLds) {
+    delete p;
+    return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS per workgroup than supported (T or K too large)");
+  }
+  auto fail = [&](hipError_t e, const char* what) {
+    abn_plan_destroy(p);
+    return set_err(c, ABN_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  };
+  rc = upload_topology(c, p->topo, p->dtopo);
+  if (rc) {
+    abn_plan_destroy(p);
+    return rc;
+  }
+  const size_t W = (size_t)n_windows, N = (size_t)n_rows, S = (size_t)n_starts, B = (size_t)n_boot;
+  hipError_t e;
+#define PALLOC(buf, count)                         \
+  if ((e = p->buf.alloc(count)) != hipSuccess) return fail(e, "hipMalloc " #buf)
+  PALLOC(D, W * N);
+  PALLOC(pred, W * N);
+  PALLOC(resid, W * N);
+  PALLOC(p_uu, W);
+  PALLOC(eqp, W);
+  PALLOC(eqp_w, W);
+  PALLOC(model, W * 4);
+  PALLOC(best_start, W);
+  PALLOC(simplexA, W * S * 20);
+  PALLOC(bestA, W * S * 4);
+  PALLOC(infoA, W * S);
+  PALLOC(lse, W * S);
+  PALLOC(idx, W * B * N);
+  PALLOC(bestB, W * B * 4);
+  PALLOC(infoB, W * B);
+  PALLOC(raw_own, W * B * 7);
+#undef PALLOC
+  p->raw = p->raw_own.p;
+  for (auto& ev : p->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) return fail(e, "hipEventCreate");
+  *out = p;
+  return ABN_OK;
+}
+
+static int plan_upload_model(abn_plan* p, const double* model, const double* pred, const double* resid,
+                             const double* p0uu, const double* eqp, const double* eqp_w) {
+  abn_ctx* c = p->ctx;
+  const size_t W = (size_t)p->W;
+  HIPCHK(c, hipMemcpyAsync(p->model.p, model, p->model.bytes(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(p->pred.p, pred, p->pred.bytes(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(p->resid.p, resid, p->resid.bytes(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(p->p_uu.p, p0uu, W * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(p->eqp.p, eqp, W * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(p->eqp_w.p, eqp_w, W * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  int rc = launch_gen_idx(c, p->idx.p, p->N, p->B, p->W, p->opt.seed, p->window_offset, p->boot_offset);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  p->windows_set = true;
+  p->phase_a_done = true;
+  return ABN_OK;
+}
+
+extern "C" int abn_plan_set_windows(abn_plan* p, const double* d_obs, const double* p0uu, const double* eqp,
+                                    const double* eqp_weight) {
+  if (!p) return ABN_ERR_INVALID_ARG;
+  abn_ctx* c = p->ctx;
+  if (!d_obs || !p0uu) return set_err(c, ABN_ERR_INVALID_ARG, "null window data");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t W = (size_t)p->W, N = (size_t)p->N, S = (size_t)p->S;
+  std::vector<double> ones(W, 1.0);  // eqp_weight = 1.0, src/alphabeta.rs:37,50
+  const double* e1 = eqp ? eqp : p0uu;  // eqp = p0uu, src/alphabeta.rs:36,49
+  const double* e2 = eqp_weight ? eqp_weight : ones.data();
+  HIPCHK(c, hipMemcpyAsync(p->D.p, d_obs, p->D.bytes(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(p->p_uu.p, p0uu, W * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(p->eqp.p, e1, W * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(p->eqp_w.p, e2, W * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  std::vector<double> sx(W * S * 20);
+  for (size_t w = 0; w < W; ++w) {
+    double mx = d_obs[w * N];  // max of column 3, src/ab_neutral.rs:25-29
+    for (size_t i = 1; i < N; ++i) mx = std::max(mx, d_obs[w * N + i]);
+    abn_gen_start_simplices(p->opt.seed, p->window_offset + (uint32_t)w, p->S, mx, sx.data() + w * S * 20);
+  }
+  if (!sx.empty())
+    HIPCHK(c, hipMemcpyAsync(p->simplexA.p, sx.data(), p->simplexA.bytes(), hipMemcpyHostToDevice, c->stream));
+  int rc = launch_gen_idx(c, p->idx.p, p->N, p->B, p->W, p->opt.seed, p->window_offset, p->boot_offset);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // sx / ones are host temporaries
+  p->windows_set = true;
+  p->phase_a_done = false;
+  return ABN_OK;
+}
+
+static void fill_common(const abn_plan* p, FitArgs& a) {
+  a.tri = p->dtopo.tri.p;
+  a.tid = p->dtopo.tid.p;
+  a.N = p->N;
+  a.K = p->topo.K;
+  a.T = p->topo.T;
+  a.TP = p->topo.TP;
+  a.chain_stride = p->topo.chain_stride;
+  a.p_uu = p->p_uu.p;
+  a.eqp = p->eqp.p;
+  a.eqp_w = p->eqp_w.p;
+  a.wstride = 1;
+  a.D = p->D.p;
+  a.pred = p->pred.p;
+  a.resid = p->resid.p;
+  a.idx = p->idx.p;
+  a.model = p->model.p;
+  a.seed = p->opt.seed;
+  a.window_offset = p->window_offset;
+  a.boot_offset = p->boot_offset;
+  a.W = p->W;
+  a.shrink_variant = p->opt.shrink_on_failed_contraction ? 1 : 0;
+  a.sd_tol = p->opt.sd_tolerance;
+}
+
+extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
+  if (!p) return ABN_ERR_INVALID_ARG;
+  abn_ctx* c = p->ctx;
+  if (!p->windows_set) return set_err(c, ABN_ERR_STATE, "abn_plan_set_windows has not been called");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (phase == 0) {
+    if (p->S <= 0) return set_err(c, ABN_ERR_STATE, "plan has no starts");
+    FitArgs a{};
+    fill_common(p, a);
+    a.dmode = 0;
+    a.smode = 0;
+    a.simplex0 = p->simplexA.p;
+    a.C = p->S;
+    a.max_iters = p->opt.max_iters_start;
+    a.best = p->bestA.p;
+    a.info = p->infoA.p;
+    a.raw = nullptr;
+    HIPCHK(c, hipEventRecord(p->ev[0], c->stream));
+    int rc = launch_fit(c, a, p->lanes);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(p->ev[1], c->stream));
+    SelectArgs s{};
+    s.tri = a.tri;
+    s.tid = a.tid;
+    s.N = a.N;
+    s.K = a.K;
+    s.T = a.T;
+    s.TP = a.TP;
+    s.p_uu = p->p_uu.p;
+    s.D = p->D.p;
+    s.models = p->bestA.p;
+    s.info = p->infoA.p;
+    s.W = p->W;
+    s.S = p->S;
+    s.lse = p->lse.p;
+    s.model = p->model.p;
+    s.pred = p->pred.p;
+    s.resid = p->resid.p;
+    s.best_start = p->best_start.p;
+    const size_t lds = ((size_t)9 * a.TP + p->topo.KP + kSelChunk) * sizeof(double);
+    HIPCHK(c, hipEventRecord(p->ev[2], c->stream));
+    hipLaunchKernelGGL(abn_select_kernel, dim3((unsigned)p->W), dim3(kWave), lds, c->stream, s);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(p->ev[3], c->stream));
+    p->phase_a_done = true;
+    p->ran_a = true;
+    return ABN_OK;
+  }
+  if (phase == 1) {
+    if (p->B <= 0) return set_err(c, ABN_ERR_STATE, "plan has no bootstraps");
+    if (!p->phase_a_done) return set_err(c, ABN_ERR_STATE, "phase A has not run");
+    FitArgs a{};
+    fill_common(p, a);
+    a.dmode = 1;
+    a.smode = 1;
+    a.C = p->B;
+    a.max_iters = p->opt.max_iters_boot;
+    a.best = p->bestB.p;
+    a.info = p->infoB.p;
+    a.raw = p->raw;
+    HIPCHK(c, hipEventRecord(p->ev[4], c->stream));
+    int rc = launch_fit(c, a, p->lanes);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(p->ev[5], c->stream));
+    p->ran_b = true;
+    return ABN_OK;
+  }
+  return set_err(c, ABN_ERR_INVALID_ARG, "phase must be 0 or 1");
+}
+
+extern "C" int abn_plan_run(abn_plan* p) {
+  if (!p) return ABN_ERR_INVALID_ARG;
+  int rc = ABN_OK;
+  if (p->S > 0) rc = abn_plan_run_phase(p, 0);
+  if (rc) return rc;
+  if (p->B > 0) rc = abn_plan_run_phase(p, 1);
+  return rc;
+}
+
+extern "C" int abn_plan_sync(abn_plan* p) {
+  if (!p) return ABN_ERR_INVALID_ARG;
+  HIPCHK(p->ctx, hipStreamSynchronize(p->ctx->stream));
+  return ABN_OK;
+}
+
+extern "C" int abn_plan_kernel_ms(abn_plan* p, double* ms3) {
+  if (!p || !ms3) return ABN_ERR_INVALID_ARG;
+  abn_ctx* c = p->ctx;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  ms3[0] = ms3[1] = ms3[2] = 0.0;
+  float ms = 0.f;
+  if (p->ran_a) {
+    HIPCHK(c, hipEventElapsedTime(&ms, p->ev[0], p->ev[1]));
+    ms3[0] = ms;
+    HIPCHK(c, hipEventElapsedTime(&ms, p->ev[2], p->ev[3]));
+    ms3[1] = ms;
+  }
+  if (p->ran_b) {
+    HIPCHK(c, hipEventElapsedTime(&ms, p->ev[4], p->ev[5]));
+    ms3[2] = ms;
+  }
+  return ABN_OK;
+}
+
+extern "C" int abn_plan_raw_device_ptr(abn_plan* p, void** dev_ptr) {
+  if (!p || !dev_ptr) return ABN_ERR_INVALID_ARG;
+  *dev_ptr = p->raw;
+  return ABN_OK;
+}
+
+extern "C" int abn_plan_bind_raw(abn_plan* p, void* dev_ptr) {
+  if (!p) return ABN_ERR_INVALID_ARG;
+  p->raw = dev_ptr ? (double*)dev_ptr : p->raw_own.p;
+  return ABN_OK;
+}
+
+extern "C" int abn_plan_download(abn_plan* p, double* models, double* pred, double* resid, double* raw,
+                                 abn_fit_info* info_a, abn_fit_info* info_b, int32_t* best_start) {
+  if (!p) return ABN_ERR_INVALID_ARG;
+  abn_ctx* c = p->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipStream_t s = c->stream;
+  const size_t W = (size_t)p->W, B = (size_t)p->B;
+  if (models) HIPCHK(c, hipMemcpyAsync(models, p->model.p, p->model.bytes(), hipMemcpyDeviceToHost, s));
+  if (pred) HIPCHK(c, hipMemcpyAsync(pred, p->pred.p, p->pred.bytes(), hipMemcpyDeviceToHost, s));
+  if (resid) HIPCHK(c, hipMemcpyAsync(resid, p->resid.p, p->resid.bytes(), hipMemcpyDeviceToHost, s));
+  if (raw && B) HIPCHK(c, hipMemcpyAsync(raw, p->raw, W * B * 7 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (info_a && p->S) HIPCHK(c, hipMemcpyAsync(info_a, p->infoA.p, p->infoA.bytes(), hipMemcpyDeviceToHost, s));
+  if (info_b && B) HIPCHK(c, hipMemcpyAsync(info_b, p->infoB.p, p->infoB.bytes(), hipMemcpyDeviceToHost, s));
+  if (best_start)
+    HIPCHK(c, hipMemcpyAsync(best_start, p->best_start.p, p->best_start.bytes(), hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  return ABN_OK;
+}
+
+extern "C" int abn_plan_counters(abn_plan* p, int64_t* out3) {
+  if (!p || !out3) return ABN_ERR_INVALID_ARG;
+  abn_ctx* c = p->ctx;
+  out3[0] = out3[1] = out3[2] = 0;
+  std::vector<FitInfoDev> h;
+  auto add = [&](const DevBuf<FitInfoDev>& b) -> int {
+    if (!b.n) return ABN_OK;
+    h.resize(b.n);
+    HIPCHK(c, hipMemcpyAsync(h.data(), b.p, b.bytes(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (const auto& f : h) {
+      out3[0] += 1;
+      out3[1] += f.evals;
+      out3[2] += f.iters;
+    }
+    return ABN_OK;
+  };
+  int rc = ABN_OK;
+  if (p->ran_a) rc = add(p->infoA);
+  if (rc) return rc;
+  if (p->ran_b) rc = add(p->infoB);
+  return rc;
+}
+
+extern "C" int abn_plan_device_bytes(abn_plan* p, int64_t* bytes) {
+  if (!p || !bytes) return ABN_ERR_INVALID_ARG;
+  size_t t = 0;
+  t += p->D.bytes() + p->pred.bytes() + p->resid.bytes() + p->p_uu.bytes() + p->eqp.bytes() + p->eqp_w.bytes();
+  t += p->simplexA.bytes() + p->bestA.bytes() + p->model.bytes() + p->lse.bytes() + p->bestB.bytes();
+  t += p->raw_own.bytes() + p->infoA.bytes() + p->infoB.bytes() + p->best_start.bytes() + p->idx.bytes();
+  t += p->dtopo.tri.bytes() + p->dtopo.tid.bytes();
+  *bytes = (int64_t)t;
+  return ABN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// (2) ab_neutral::run and (3) boot_model::run on host buffers
+// ------------------------------------------------------------------------------------------------
+static void split_pedigree(const double* ped, int n, std::vector<double>& gens, std::vector<double>& d) {
+  gens.resize((size_t)n * 3);
+  d.resize((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    gens[(size_t)i * 3 + 0] = ped[(size_t)i * 4 + 0];
+    gens[(size_t)i * 3 + 1] = ped[(size_t)i * 4 + 1];
+    gens[(size_t)i * 3 + 2] = ped[(size_t)i * 4 + 2];
+    d[(size_t)i] = ped[(size_t)i * 4 + 3];
+  }
+}
+
+extern "C" int abn_ab_neutral_run(abn_ctx* c, const abn_options* opts, const double* pedigree, int32_t n_rows,
+                                  double p0uu, double eqp, double eqp_weight, int32_t n_starts, double* model,
+                                  double* pred, double* resid, double* all_models, abn_fit_info* info, double* lse) {
+  if (!c) return ABN_ERR_INVALID_ARG;
+  if (!pedigree || n_rows <= 0 || n_starts <= 0 || !model || !pred || !resid)
+    return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
+  std::vector<double> gens, d;
+  split_pedigree(pedigree, n_rows, gens, d);
+  abn_plan* p = nullptr;
+  int rc = abn_plan_create(c, opts, gens.data(), n_rows, 1, n_starts, 0, 0, 0, &p);
+  if (rc) return rc;
+  rc = abn_plan_set_windows(p, d.data(), &p0uu, &eqp, &eqp_weight);
+  if (!rc) rc = abn_plan_run_phase(p, 0);
+  int32_t best = -1;
+  if (!rc) rc = abn_plan_download(p, model, pred, resid, nullptr, info, nullptr, &best);
+  if (!rc && all_models) {
+    hipError_t e = hipMemcpy(all_models, p->bestA.p, p->bestA.bytes(), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = set_err(c, ABN_ERR_HIP, hipGetErrorString(e));
+  }
+  if (!rc && lse) {
+    hipError_t e = hipMemcpy(lse, p->lse.p, p->lse.bytes(), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = set_err(c, ABN_ERR_HIP, hipGetErrorString(e));
+  }
+  abn_plan_destroy(p);
+  if (!rc && best < 0) rc = set_err(c, ABN_ERR_NO_FINITE_FIT, abn_status_string(ABN_ERR_NO_FINITE_FIT));
+  return rc;
+}
+
+extern "C" int abn_boot_model_run(abn_ctx* c, const abn_options* opts, const double* pedigree, int32_t n_rows,
+                                  const double* model, const double* pred, const double* resid, double p0uu,
+                                  double eqp, double eqp_weight, int32_t n_boot, double* raw, abn_fit_info* info) {
+  if (!c) return ABN_ERR_INVALID_ARG;
+  if (!pedigree || n_rows <= 0 || n_boot <= 0 || !model || !pred || !resid || !raw)
+    return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
+  std::vector<double> gens, d;
+  split_pedigree(pedigree, n_rows, gens, d);
+  abn_plan* p = nullptr;
+  int rc = abn_plan_create(c, opts, gens.data(), n_rows, 1, 0, n_boot, 0, 0, &p);
+  if (rc) return rc;
+  rc = plan_upload_model(p, model, pred, resid, &p0uu, &eqp, &eqp_weight);
+  if (!rc) rc = abn_plan_run_phase(p, 1);
+  if (!rc) rc = abn_plan_download(p, nullptr, nullptr, nullptr, raw, nullptr, info, nullptr);
+  abn_plan_destroy(p);
+  return rc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// src/analysis.rs:50-98 on the host (ndarray mean / Welford std with mul_add, ndarray-stats Linear CI)
+// ------------------------------------------------------------------------------------------------
+extern "C" int abn_analyze(const double* raw, int64_t n_boot, double* out32) {
+  if (!raw || !out32 || n_boot <= 0) return ABN_ERR_INVALID_ARG;
+  const size_t B = (size_t)n_boot;
+  std::vector<double> col(B), sorted(B);
+  static const int src_col[8] = {0, 1, -1, 2, 3, 4, 5, 6};
+  for (int k = 0; k < 8; ++k) {
+    const int cidx = src_col[k];
+    for (size_t i = 0; i < B; ++i)
+      col[i] = cidx < 0 ? raw[7 * i + 1] / raw[7 * i + 0] : raw[7 * i + (size_t)cidx];  // beta / alpha, :54
+    double mean;
+    if (cidx < 0) {  // contiguous Array1 -> ndarray's eight-lane unrolled fold
+      double part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      size_t i = 0;
+      for (; i + 8 <= B; i += 8)
+        for (int q = 0; q < 8; ++q) part[q] = part[q] + col[i + (size_t)q];
+      double acc = 0.0;
+      acc = acc + (part[0] + part[4]);
+      acc = acc + (part[1] + part[5]);
+      acc = acc + (part[2] + part[6]);
+      acc = acc + (part[3] + part[7]);
+      for (; i < B; ++i) acc = acc + col[i];
+      mean = acc / (double)B;
+    } else {  // strided column view -> plain fold
+      double acc = 0.0;
+      for (size_t i = 0; i < B; ++i) acc = acc + col[i];
+      mean = acc / (double)B;
+    }
+    double wmean = 0.0, sum_sq = 0.0;
+    for (size_t i = 0; i < B; ++i) {
+      const double delta = col[i] - wmean;
+      wmean = wmean + delta / (double)(i + 1);
+      sum_sq = std::fma(col[i] - wmean, delta, sum_sq);
+    }
+    const double sd = std::sqrt(sum_sq / ((double)B - 1.0));
+    sorted = col;
+    std::sort(sorted.begin(), sorted.end());
+    const double qs[2] = {0.025, 0.975};
+    double ci[2];
+    for (int q = 0; q < 2; ++q) {
+      const double fi = qs[q] * (double)(B - 1);
+      const size_t lo = (size_t)std::floor(fi), hi = (size_t)std::ceil(fi);
+      const double frac = fi - std::trunc(fi);
+      ci[q] = sorted[lo] + frac * (sorted[hi] - sorted[lo]);
+    }
+    out32[k] = mean;
+    out32[8 + k] = sd;
+    out32[16 + k] = ci[0];
+    out32[24 + k] = ci[1];
+  }
+  return ABN_OK;
+}

@@ -1,0 +1,720 @@
+// Device code of the ABneutral hot path for gfx950 (CDNA4, wave64).  Compiled with -ffp-contract=off:
+// every fused multiply-add below is explicit and corresponds to one the reference executes.
+//
+// Mapping: a Nelder-Mead chain (one fit) is owned by a group of G lanes of one
+// wavefront (G = 64: one wavefront per chain; G < 64 packs 64/G chains into a wavefront for small
+// pedigrees).  Workgroups are ONE wavefront (64 threads) so chains in different wavefronts never
+// synchronise.  All groups of a wavefront advance in lock-step, one cost evaluation per step
+// ("evaluation-synchronous" state machines), so the expensive part — the cost function — never diverges.
+//
+// One cost evaluation (Problem::cost, src/structs.rs:194-216) for candidate x = (alpha,beta,weight,c):
+//   P1  genmatrix(alpha,beta)                          src/divergence.rs:96-114      (all lanes)
+//   P2  power table G^0..G^T, left-accumulated         src/divergence.rs:16-31       (lane r<3 = row r)
+//       -> LDS, pw[k][9]
+//   P3  per DISTINCT (t0,t1-t0,t2-t0) triple: dt1t2    src/divergence.rs:51-90       (lane per triple)
+//       -> LDS dt[K]   (rows sharing a triple share the value bit for bit)
+//   P4  per row: (D_i - c - dt[tid_i])^2 + penalty     src/structs.rs:208-213        (lane per row)
+//   P5  xor-butterfly over the G lanes                 (the oracle's `lanes=G` order)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "abn_philox.h"
+
+namespace abn {
+
+constexpr int kWave = 64;
+
+// ---- fit states of the evaluation-synchronous Nelder-Mead machine
+constexpr int ST_INIT0 = 0;     // 0..4: evaluating start vertex k           (argmin Solver::init)
+constexpr int ST_REFLECT = 5;   // evaluating the reflected point
+constexpr int ST_EXPAND = 6;    // evaluating the expanded point
+constexpr int ST_CONTRACT = 7;  // evaluating the contracted point
+constexpr int ST_SHRINK1 = 8;   // 8..11: evaluating shrunk vertex k = st-7
+constexpr int ST_DONE = 12;
+
+struct FitInfoDev {  // layout of abn_fit_info (include/abneutral.h)
+  double best_cost;
+  int32_t iters;
+  int32_t evals;
+  int32_t status;
+  int32_t lanes;
+};
+
+struct FitArgs {
+  // pedigree topology (shared by all windows)
+  const uint32_t* tri;   // [K] t0 | (t1-t0)<<8 | (t2-t0)<<16
+  const uint16_t* tid;   // [N] row -> triple
+  int N, K, T, TP;       // TP = table pitch (>= T+1)
+  int chain_stride;      // doubles of LDS per chain: 9*TP + KP
+  // per-window data; wstride = 0 broadcasts window 0's scalars to every chain
+  const double* p_uu;    // [W] p0uu
+  const double* eqp;     // [W]
+  const double* eqp_w;   // [W]
+  int wstride;
+  // observed divergences
+  int dmode;             // 0: D[w*N+i]   1: pred[w*N+i] + resid[w*N + idx[(w*C+j)*N+i]]
+  const double* D;
+  const double* pred;
+  const double* resid;
+  const uint32_t* idx;
+  // start simplices
+  int smode;             // 0: simplex0[chain*20]   1: [model[w], vary() x4] from Philox
+  const double* simplex0;
+  const double* model;   // [W*4]
+  uint64_t seed;
+  uint32_t window_offset, boot_offset;
+  // chains: W windows x C chains
+  int W, C;
+  int max_iters;
+  int shrink_variant;
+  double sd_tol;
+  // outputs (fit order)
+  double* best;          // [W*C*4]
+  FitInfoDev* info;      // [W*C]
+  double* raw;           // nullable [W*C*7] (src/boot_model.rs:86-91)
+};
+
+// ------------------------------------------------------------------------------------------------
+// scalar pieces
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double fma3(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// src/divergence.rs:96-114 (powi(2) = x*x).  Named scalars, not an array: a lane-dependent choice of row
+// must stay a v_cndmask on registers and never become an indexed (scratch) load.
+struct Gen {
+  double g0, g1, g2, g3, g4, g5, g6, g7, g8;
+};
+__device__ __forceinline__ Gen genmatrix(double alpha, double beta) {
+  Gen G;
+  G.g0 = (1.0 - alpha) * (1.0 - alpha);
+  G.g1 = 2.0 * (1.0 - alpha) * alpha;
+  G.g2 = alpha * alpha;
+  G.g3 = 0.25 * ((beta + 1.0 - alpha) * (beta + 1.0 - alpha));
+  G.g4 = 0.5 * (beta + 1.0 - alpha) * (alpha + 1.0 - beta);
+  G.g5 = 0.25 * ((alpha + 1.0 - beta) * (alpha + 1.0 - beta));
+  G.g6 = beta * beta;
+  G.g7 = 2.0 * (1.0 - beta) * beta;
+  G.g8 = (1.0 - beta) * (1.0 - beta);
+  return G;
+}
+
+// src/alphabeta.rs:62-65
+__device__ __forceinline__ double p_uu_est(double alpha, double beta) {
+  return (beta * ((1.0 - beta) * (1.0 - beta) - (1.0 - alpha) * (1.0 - alpha) - 1.0)) /
+         ((alpha + beta) * ((alpha + beta - 1.0) * (alpha + beta - 1.0) - 2.0));
+}
+// src/structs.rs:146-149
+__device__ __forceinline__ double est_mm(double alpha, double beta) {
+  return (alpha * ((1.0 - alpha) * (1.0 - alpha) - (1.0 - beta) * (1.0 - beta) - 1.0)) /
+         ((alpha + beta) * ((alpha + beta - 1.0) * (alpha + beta - 1.0) - 2.0));
+}
+// src/structs.rs:151-154
+__device__ __forceinline__ double est_um(double alpha, double beta) {
+  return (4.0 * alpha * beta * (alpha + beta - 2.0)) /
+         ((alpha + beta) * ((alpha + beta - 1.0) * (alpha + beta - 1.0) - 2.0));
+}
+
+// xor-butterfly over the G lanes of a group; every lane ends with the same sum.
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int off = 1; off < G; off <<= 1) v = v + __shfl_xor(v, off, kWave);
+  return v;
+}
+
+// P2: lanes gl = 0,1,2 of a group own rows UU, UM, MM of the running power (row r of G^k depends only
+// on row r of G^(k-1): result.dot(matrix), src/divergence.rs:28).  Each product element is
+// fma(a_i2,b_2j, fma(a_i1,b_1j, fma(a_i0,b_0j, 0))) — matrixmultiply's k-ascending FMA accumulation.
+__device__ __forceinline__ void build_power_table(Gen Gm, int T, int TP, double* pw, int gl) {
+  // Opaque register copies: without them hipcc rewrites the lane-dependent row selects below into an
+  // indexed load from a scratch copy of the matrix.
+  asm("" : "+v"(Gm.g0), "+v"(Gm.g1), "+v"(Gm.g2));
+  asm("" : "+v"(Gm.g3), "+v"(Gm.g4), "+v"(Gm.g5));
+  asm("" : "+v"(Gm.g6), "+v"(Gm.g7), "+v"(Gm.g8));
+  const bool wr = gl < 3;
+  const bool is1 = (gl == 1), is2 = (gl == 2);  // every other lane mirrors row 0 and never stores
+  double r0 = (is1 || is2) ? 0.0 : 1.0, r1 = is1 ? 1.0 : 0.0, r2 = is2 ? 1.0 : 0.0;  // :21-24
+  double* prow = pw + 3 * (wr ? gl : 0);  // table layout pw[k][9]: entry k at k*9, row r at +3r
+  if (wr) {
+    prow[0] = r0;
+    prow[1] = r1;
+    prow[2] = r2;
+  }
+  if (T >= 1) {
+    r0 = is2 ? Gm.g6 : (is1 ? Gm.g3 : Gm.g0);  // matrix.clone(), :25
+    r1 = is2 ? Gm.g7 : (is1 ? Gm.g4 : Gm.g1);
+    r2 = is2 ? Gm.g8 : (is1 ? Gm.g5 : Gm.g2);
+    if (wr) {
+      prow[9 + 0] = r0;
+      prow[9 + 1] = r1;
+      prow[9 + 2] = r2;
+    }
+    for (int k = 2; k <= T; ++k) {  // :27-29
+      const double n0 = fma3(r2, Gm.g6, fma3(r1, Gm.g3, fma3(r0, Gm.g0, 0.0)));
+      const double n1 = fma3(r2, Gm.g7, fma3(r1, Gm.g4, fma3(r0, Gm.g1, 0.0)));
+      const double n2 = fma3(r2, Gm.g8, fma3(r1, Gm.g5, fma3(r0, Gm.g2, 0.0)));
+      r0 = n0;
+      r1 = n1;
+      r2 = n2;
+      if (wr) {
+        prow[9 * k + 0] = r0;
+        prow[9 * k + 1] = r1;
+        prow[9 * k + 2] = r2;
+      }
+    }
+  }
+}
+
+// conditional divergence of one start state, src/divergence.rs:68-87 (this exact association)
+__device__ __forceinline__ double cond_div(double a0, double a1, double a2, double b0, double b1, double b2) {
+  return 0.5 * (a0 * b1 + a1 * b0 + a1 * b2 + a2 * b1) + (a0 * b2 + a2 * b0);
+}
+
+// P3 for one distinct triple, src/divergence.rs:52-89
+__device__ __forceinline__ double triple_dt(uint32_t tr, const double* pw, int TP, double sv0, double sv1,
+                                            double sv2) {
+  const int t0 = tr & 0xff, ea = (tr >> 8) & 0xff, eb = (tr >> 16) & 0xff;
+  double P[9], A[9], B[9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {  // pitch 9 doubles = 18 banks: 32 distinct exponents never conflict
+    P[e] = pw[t0 * 9 + e];
+    A[e] = pw[ea * 9 + e];
+    B[e] = pw[eb * 9 + e];
+  }
+  // svt0 = sv_gzero.t().dot(G^t0), :55
+  const double s0 = fma3(sv2, P[6], fma3(sv1, P[3], fma3(sv0, P[0], 0.0)));
+  const double s1 = fma3(sv2, P[7], fma3(sv1, P[4], fma3(sv0, P[1], 0.0)));
+  const double s2 = fma3(sv2, P[8], fma3(sv1, P[5], fma3(sv0, P[2], 0.0)));
+  const double d_mm = cond_div(A[6], A[7], A[8], B[6], B[7], B[8]);  // :68-73
+  const double d_um = cond_div(A[3], A[4], A[5], B[3], B[4], B[5]);  // :75-80
+  const double d_uu = cond_div(A[0], A[1], A[2], B[0], B[1], B[2]);  // :82-87
+  return s0 * d_uu + s1 * d_um + s2 * d_mm;                          // :89
+}
+
+// ------------------------------------------------------------------------------------------------
+// Simplex bookkeeping, "dimension per lane".  Nelder-Mead's vector algebra is element-wise over the four
+// parameters, so lane gl of a group keeps ONE parameter dimension d = gl & 3 of all five vertices, in
+// rank order (vx[0] best ... vx[4] worst), next to a replicated copy of the five costs.  Everything is
+// statically indexed (registers only).  The candidate is re-assembled for the cost function with four
+// lane broadcasts per evaluation.
+// ------------------------------------------------------------------------------------------------
+// Insert element I into the sorted prefix [0, I): the inner step of std's stable insertion sort
+// (len <= 20), is_less(a,b) = a.cost < b.cost; a NaN compares Equal, i.e. never moves.
+template <int I>
+__device__ __forceinline__ void insert_tail(double (&c)[5], double (&v)[5]) {
+  const double fi = c[I], xi = v[I];
+  bool b[I];
+  b[I - 1] = fi < c[I - 1];
+#pragma unroll
+  for (int j = I - 2; j >= 0; --j) b[j] = b[j + 1] && (fi < c[j]);
+  double nc[I + 1], nv[I + 1];
+  nc[I] = b[I - 1] ? c[I - 1] : fi;
+  nv[I] = b[I - 1] ? v[I - 1] : xi;
+#pragma unroll
+  for (int j = I - 1; j >= 1; --j) {
+    nc[j] = b[j - 1] ? c[j - 1] : (b[j] ? fi : c[j]);
+    nv[j] = b[j - 1] ? v[j - 1] : (b[j] ? xi : v[j]);
+  }
+  nc[0] = b[0] ? fi : c[0];
+  nv[0] = b[0] ? xi : v[0];
+#pragma unroll
+  for (int j = 0; j <= I; ++j) {
+    c[j] = nc[j];
+    v[j] = nv[j];
+  }
+}
+__device__ __forceinline__ void sort5(double (&c)[5], double (&v)[5]) {
+  insert_tail<1>(c, v);
+  insert_tail<2>(c, v);
+  insert_tail<3>(c, v);
+  insert_tail<4>(c, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fit kernel.  RMAX > 0: "register mode" — each lane keeps its rows' observed divergences, row->
+// triple ids and its triples in registers for the whole fit (needs N <= G*RMAX); per evaluation the
+// only memory touched is the chain's LDS scratch.  RMAX == 0: "stream mode" for large pedigrees —
+// rows and triples are re-read every evaluation (bootstrap: the u32 index row is re-streamed).
+// ------------------------------------------------------------------------------------------------
+template <int G, int RMAX>
+__global__ __launch_bounds__(kWave) void abn_fit_kernel(const FitArgs a) {
+  constexpr int NG = kWave / G;
+  constexpr int RR = RMAX > 0 ? RMAX : 1;
+  extern __shared__ __align__(16) double lds[];
+
+  const int lane = threadIdx.x;
+  const int g = lane / G;
+  const int gl = lane - g * G;
+  const int gbase = g * G;
+  const int dim = gl & 3;
+  const long long total = (long long)a.W * a.C;
+  const long long chain_raw = (long long)blockIdx.x * NG + g;
+  const bool valid = chain_raw < total;
+  const long long chain = valid ? chain_raw : 0;
+  const int w = (int)(chain / a.C);
+  const int j = (int)(chain - (long long)w * a.C);
+  const int N = a.N, K = a.K, TP = a.TP;
+
+  double* pw = lds + (size_t)g * a.chain_stride;
+  double* dtab = pw + 9 * TP;
+
+  const int wi = w * a.wstride;
+  const double p_uu0 = a.p_uu[wi];
+  const double p_mm = 1.0 - p_uu0;                    // src/ab_neutral.rs:23
+  const double eqp = a.eqp[wi];
+  const double ewN = a.eqp_w[wi] * (double)N;         // eqp_weight * nrows, src/structs.rs:210-211
+  const size_t wN = (size_t)w * (size_t)N;
+  const uint32_t* idx_row = a.dmode ? a.idx + (size_t)chain * (size_t)N : nullptr;
+
+  // ---- stage this lane's rows / triples (register mode)
+  double Dv[RR];
+  uint32_t tidv[RR], triv[RR];
+  if (RMAX > 0) {
+#pragma unroll
+    for (int q = 0; q < RR; ++q) {
+      const int i = gl + G * q;
+      Dv[q] = 0.0;
+      tidv[q] = 0;
+      triv[q] = 0;
+      if (i < N) {
+        tidv[q] = a.tid[i];
+        Dv[q] = a.dmode ? a.pred[wN + i] + a.resid[wN + idx_row[i]]  // src/boot_model.rs:50-54
+                        : a.D[wN + i];
+      }
+      if (i < K) triv[q] = a.tri[i];
+    }
+  }
+
+  // ---- start simplex: this lane's dimension of the five vertices
+  double vx[5], c[5];
+  if (a.smode == 0) {
+    const double* s0 = a.simplex0 + (size_t)chain * 20;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) vx[k] = s0[4 * k + dim];
+  } else {  // [params, vary() x4], src/boot_model.rs:69-75
+    const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+    const uint32_t wg = a.window_offset + (uint32_t)w, bg = a.boot_offset + (uint32_t)j;
+    vx[0] = a.model[4 * w + dim];
+#pragma unroll
+    for (int v = 1; v < 5; ++v) {
+      uint32_t r[4];
+      philox4x32_10((uint32_t)(v - 1) * 2u + (uint32_t)(dim >> 1), bg, wg, kTagJitter, k0, k1, r);
+      const uint32_t r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+      const bool odd = (dim & 1) != 0;
+      vx[v] = vary_one(vx[0], odd ? r2 : r0, odd ? r3 : r1);
+    }
+  }
+
+  // ---- one cost evaluation; xd = this lane's dimension of its group's candidate
+  auto eval = [&](double xd) -> double {
+    const double al = __shfl(xd, gbase + 0, kWave), be = __shfl(xd, gbase + 1, kWave);
+    const double wt = __shfl(xd, gbase + 2, kWave), ic = __shfl(xd, gbase + 3, kWave);
+    const Gen Gm = genmatrix(al, be);                        // P1
+    const double sv0 = p_uu0, sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;  // src/divergence.rs:44
+    build_power_table(Gm, a.T, TP, pw, gl);                  // P2
+    __syncthreads();
+    if (RMAX > 0) {                                          // P3
+#pragma unroll
+      for (int q = 0; q < RR; ++q) {
+        const int t = gl + G * q;
+        if (t < K) dtab[t] = triple_dt(triv[q], pw, TP, sv0, sv1, sv2);
+        __builtin_amdgcn_sched_barrier(0);  // one triple's 27 table reads at a time (VGPR pressure)
+      }
+    } else {
+      for (int t = gl; t < K; t += G) dtab[t] = triple_dt(a.tri[t], pw, TP, sv0, sv1, sv2);
+    }
+    __syncthreads();
+    const double puu = p_uu_est(al, be);                     // src/divergence.rs:92
+    const double pen = ewN * ((puu - eqp) * (puu - eqp));    // src/structs.rs:210-212
+    double acc = 0.0;                                        // P4
+    if (RMAX > 0) {
+#pragma unroll
+      for (int q = 0; q < RR; ++q) {
+        const int i = gl + G * q;
+        if (i < N) {
+          const double r = Dv[q] - ic - dtab[tidv[q]];
+          acc = acc + (r * r + pen);
+        }
+      }
+    } else {
+      for (int i = gl; i < N; i += G) {
+        const double d = a.dmode ? a.pred[wN + i] + a.resid[wN + idx_row[i]] : a.D[wN + i];
+        const double r = d - ic - dtab[a.tid[i]];
+        acc = acc + (r * r + pen);
+      }
+    }
+    acc = group_sum<G>(acc);                                 // P5
+    __syncthreads();
+    return acc;
+  };
+
+  // ---- evaluation-synchronous Nelder-Mead (argmin 0.8.1 NelderMead + Executor).
+  // One call site of the cost function; Solver::init and NelderMead::shrink evaluate "the vertex at a
+  // fixed position" and rotate the arrays, so no register array is ever indexed at run time.
+  int st = valid ? ST_INIT0 : ST_DONE;
+  int iter = 0, evals = 0;
+  double xc = vx[0], x0 = 0.0, xr = 0.0, bx = __builtin_nan("");
+  double fr = 0.0, best_cost = __builtin_inf();
+  bool have_best = false;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) c[k] = 0.0;
+
+  while (__ballot(st != ST_DONE) != 0ull) {
+    const double f = eval(xc);
+    bool do_sort = false, do_insert = false, do_begin = false, start_shrink = false;
+    bool count_iter = true;
+    double xi = 0.0, fi = 0.0;
+    if (st != ST_DONE) {
+      ++evals;
+      if (st <= 4) {
+        // Solver::init: costs of the five start vertices in input order
+        c[0] = f;
+        const double tc = c[0], tv = vx[0];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          c[k] = c[k + 1];
+          vx[k] = vx[k + 1];
+        }
+        c[4] = tc;
+        vx[4] = tv;
+        if (st == 4) {
+          do_sort = true;
+          do_begin = true;
+          count_iter = false;
+        } else {
+          ++st;
+          xc = vx[0];
+        }
+      } else if (st == ST_REFLECT) {
+        fr = f;
+        if (fr < c[3] && fr >= c[0]) {        // reflection accepted
+          xi = xr;
+          fi = fr;
+          do_insert = true;
+        } else if (fr < c[0]) {               // try expansion: x0 + (xr - x0) * gamma
+          xc = x0 + (xr - x0) * 2.0;
+          st = ST_EXPAND;
+        } else if (fr >= c[3]) {              // contraction towards the worst: x0 + (xw - x0) * rho
+          xc = x0 + (vx[4] - x0) * 0.5;
+          st = ST_CONTRACT;
+        } else {                              // only reachable with a NaN cost
+          start_shrink = true;
+        }
+      } else if (st == ST_EXPAND) {
+        const bool take_e = f < fr;
+        xi = take_e ? xc : xr;
+        fi = take_e ? f : fr;
+        do_insert = true;
+      } else if (st == ST_CONTRACT) {
+        if (f < c[4]) {
+          xi = xc;
+          fi = f;
+          do_insert = true;
+        } else if (a.shrink_variant) {
+          start_shrink = true;
+        } else {
+          do_begin = true;  // argmin 0.8.1: a rejected contraction leaves the simplex as it is
+        }
+      } else {
+        // NelderMead::shrink, vertex k = st - 7 just evaluated at position 1; rotate positions 1..4
+        c[1] = f;
+        const double tc = c[1], tv = vx[1];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+          c[k] = c[k + 1];
+          vx[k] = vx[k + 1];
+        }
+        c[4] = tc;
+        vx[4] = tv;
+        if (st == ST_SHRINK1 + 3) {
+          do_sort = true;
+          do_begin = true;
+        } else {
+          ++st;
+          vx[1] = vx[0] + (vx[1] - vx[0]) * 0.5;
+          xc = vx[1];
+        }
+      }
+      if (start_shrink) {  // x0 + (p - x0) * sigma with x0 = best vertex, vertices 1..4 in order
+        vx[1] = vx[0] + (vx[1] - vx[0]) * 0.5;
+        xc = vx[1];
+        st = ST_SHRINK1;
+      }
+      if (do_sort) sort5(c, vx);
+      if (do_insert) {
+        c[4] = fi;
+        vx[4] = xi;
+        insert_tail<4>(c, vx);
+        do_begin = true;
+      }
+    }
+    if (do_begin) {
+      // IterState::update(): keep the best-ever parameter vector
+      const double c_best = c[0];
+      if (c_best < best_cost || (__builtin_isinf(c_best) && __builtin_isinf(best_cost) &&
+                                 (__builtin_signbit(c_best) == __builtin_signbit(best_cost)))) {
+        bx = vx[0];
+        best_cost = c_best;
+        have_best = true;
+      }
+      if (count_iter) ++iter;
+      // terminate_internal: NelderMead::terminate (sample SD of the costs) -> max_iters -> target_cost
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) sum = sum + c[k];
+      const double c0 = sum / 5.0;
+      double ss = 0.0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) ss = ss + (c[k] - c0) * (c[k] - c0);
+      const double sd = __builtin_sqrt(1.0 / (5.0 - 1.0) * ss);
+      int status = -1;
+      if (sd < a.sd_tol) status = 0;
+      else if (iter >= a.max_iters) status = 1;
+      else if (best_cost <= -__builtin_inf()) status = 3;
+      if (status >= 0) {
+        st = ST_DONE;
+        if (!have_best) status = 2;
+        if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
+        if (gl == 0) {
+          FitInfoDev fo;
+          fo.best_cost = best_cost;
+          fo.iters = iter;
+          fo.evals = evals;
+          fo.status = status;
+          fo.lanes = G;
+          a.info[chain] = fo;
+        }
+      } else {
+        // next_iter: centroid (p0 + p1 + p2 + p3) * (1/4), reflection x0 + (x0 - worst) * alpha
+        double acc = vx[0];
+        acc = acc + vx[1];
+        acc = acc + vx[2];
+        acc = acc + vx[3];
+        x0 = acc * (1.0 / 4.0);
+        xr = x0 + (x0 - vx[4]) * 1.0;
+        xc = xr;
+        st = ST_REFLECT;
+      }
+    }
+  }
+
+  // ---- src/boot_model.rs:86-91: [alpha, beta, weight, intercept, est_mm, est_um, est_uu]
+  if (a.raw) {
+    const double b0 = __shfl(bx, gbase + 0, kWave), b1 = __shfl(bx, gbase + 1, kWave);
+    if (valid) {
+      double* ro = a.raw + (size_t)chain * 7;
+      if (gl < 4) ro[gl] = bx;
+      if (gl == 4) ro[4] = est_mm(b0, b1);
+      if (gl == 5) ro[5] = est_um(b0, b1);
+      if (gl == 6) ro[6] = p_uu_est(b0, b1);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Selection kernel: src/ab_neutral.rs:83-135.  One wavefront per window.  The pure LSE of each of the
+// S fitted models is summed SERIALLY in row order (the reference's `.sum::<f64>()`), the stable
+// arg-min taken (lowest start index on ties; NaN never wins), then predicted divergence and residuals
+// of the winner written for phase B.  LDS: chain scratch (9*TP + K doubles) + kSelChunk terms.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSelChunk = 512;
+
+struct SelectArgs {
+  const uint32_t* tri;
+  const uint16_t* tid;
+  int N, K, T, TP;
+  const double* p_uu;   // [W]
+  const double* D;      // [W*N]
+  const double* models; // [W*S*4] fitted start models
+  const FitInfoDev* info;  // [W*S]
+  int W, S;
+  double* lse;          // [W*S]
+  double* model;        // [W*4]
+  double* pred;         // [W*N]
+  double* resid;        // [W*N]
+  int32_t* best_start;  // [W]  (-1: no finite fit)
+};
+
+__global__ __launch_bounds__(kWave) void abn_select_kernel(const SelectArgs a) {
+  extern __shared__ __align__(16) double lds[];
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x;
+  const int N = a.N, K = a.K, TP = a.TP;
+  double* pw = lds;
+  double* dtab = pw + 9 * TP;
+  double* term = dtab + ((K + 1) & ~1);
+  const double p_uu0 = a.p_uu[w], p_mm = 1.0 - p_uu0;
+  const size_t wN = (size_t)w * (size_t)N;
+
+  auto fill_dt = [&](const double* x) {
+    const Gen Gm = genmatrix(x[0], x[1]);
+    const double sv0 = p_uu0, sv1 = x[2] * p_mm, sv2 = (1.0 - x[2]) * p_mm;
+    build_power_table(Gm, a.T, TP, pw, lane);
+    __syncthreads();
+    for (int t = lane; t < K; t += kWave) dtab[t] = triple_dt(a.tri[t], pw, TP, sv0, sv1, sv2);
+    __syncthreads();
+  };
+
+  int best = -1;
+  double best_lse = __builtin_inf();
+  for (int sidx = 0; sidx < a.S; ++sidx) {
+    double x[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) x[d] = a.models[((size_t)w * a.S + sidx) * 4 + d];
+    fill_dt(x);
+    double lsum = 0.0;
+    for (int base = 0; base < N; base += kSelChunk) {
+      const int cnt = (N - base) < kSelChunk ? (N - base) : kSelChunk;
+      for (int i = lane; i < cnt; i += kWave) {
+        const double r = a.D[wN + base + i] - x[3] - dtab[a.tid[base + i]];
+        term[i] = r * r;
+      }
+      __syncthreads();
+      for (int i = 0; i < cnt; ++i) lsum = lsum + term[i];
+      __syncthreads();
+    }
+    if (lane == 0) a.lse[(size_t)w * a.S + sidx] = lsum;
+    const bool ok = (lsum == lsum) && (a.info[(size_t)w * a.S + sidx].status != 2);
+    if (ok && (best < 0 || lsum < best_lse)) {
+      best = sidx;
+      best_lse = lsum;
+    }
+  }
+  if (lane == 0) a.best_start[w] = best;
+  if (best < 0) {
+    for (int i = lane; i < N; i += kWave) {
+      a.pred[wN + i] = __builtin_nan("");
+      a.resid[wN + i] = __builtin_nan("");
+    }
+    if (lane < 4) a.model[4 * w + lane] = __builtin_nan("");
+    return;
+  }
+  double x[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) x[d] = a.models[((size_t)w * a.S + best) * 4 + d];
+  fill_dt(x);
+  for (int i = lane; i < N; i += kWave) {
+    const double p = x[3] + dtab[a.tid[i]];      // src/ab_neutral.rs:123-129
+    a.pred[wN + i] = p;
+    a.resid[wN + i] = a.D[wN + i] - p;           // src/ab_neutral.rs:131-135
+  }
+  if (lane < 4) a.model[4 * w + lane] = x[lane];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Cost kernel (abn_cost_batch): one group of G lanes per candidate, any N (rows streamed).
+// strict = 1 (G must be 64): serial row-order accumulation, the reference's order exactly.
+// ------------------------------------------------------------------------------------------------
+struct CostArgs {
+  const uint32_t* tri;
+  const uint16_t* tid;
+  int N, K, T, TP;
+  int chain_stride;
+  double p_uu0, eqp, eqp_w;
+  const double* D;            // [N] (dmode 0)
+  const double* pred;         // [N]
+  const double* resid;        // [N]
+  const uint32_t* idx;        // [n_boot_rows * N]
+  const uint32_t* cand_to_boot;  // [M] or null (identity)
+  int dmode;
+  const double* cand;         // [M*4]
+  long long M;
+  int strict;
+  double* cost;               // [M]
+  double* dt;                 // nullable [M*N]
+  double* puu;                // nullable [M]
+};
+
+template <int G>
+__global__ __launch_bounds__(kWave) void abn_cost_kernel(const CostArgs a) {
+  constexpr int NG = kWave / G;
+  extern __shared__ __align__(16) double lds[];
+  const int lane = threadIdx.x;
+  const int g = lane / G;
+  const int gl = lane - g * G;
+  const long long m_raw = (long long)blockIdx.x * NG + g;
+  const bool valid = m_raw < a.M;
+  const long long m = valid ? m_raw : 0;
+  const int N = a.N, K = a.K, TP = a.TP;
+  double* pw = lds + (size_t)g * a.chain_stride;
+  double* dtab = pw + 9 * TP;
+  double* term = lds + (size_t)NG * a.chain_stride;  // strict mode only (G == 64)
+
+  const double al = a.cand[4 * m + 0], be = a.cand[4 * m + 1], wt = a.cand[4 * m + 2], ic = a.cand[4 * m + 3];
+  const double p_mm = 1.0 - a.p_uu0;
+  const uint32_t* idx_row = nullptr;
+  if (a.dmode) {
+    const size_t b = a.cand_to_boot ? a.cand_to_boot[m] : (size_t)m;
+    idx_row = a.idx + b * (size_t)N;
+  }
+  const Gen Gm = genmatrix(al, be);
+  const double sv0 = a.p_uu0, sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;
+  build_power_table(Gm, a.T, TP, pw, gl);
+  __syncthreads();
+  for (int t = gl; t < K; t += G) dtab[t] = triple_dt(a.tri[t], pw, TP, sv0, sv1, sv2);
+  __syncthreads();
+  const double puu = p_uu_est(al, be);
+  const double pen = (a.eqp_w * (double)N) * ((puu - a.eqp) * (puu - a.eqp));
+  double result;
+  if (a.strict) {
+    double ssum = 0.0;  // `square_sum += ...` in row order, src/structs.rs:206-213
+    for (int base = 0; base < N; base += kSelChunk) {
+      const int cnt = (N - base) < kSelChunk ? (N - base) : kSelChunk;
+      for (int i = gl; i < cnt; i += G) {
+        const int row = base + i;
+        const double d = a.dmode ? a.pred[row] + a.resid[idx_row[row]] : a.D[row];
+        const double r = d - ic - dtab[a.tid[row]];
+        term[i] = r * r + pen;
+      }
+      __syncthreads();
+      for (int i = 0; i < cnt; ++i) ssum = ssum + term[i];
+      __syncthreads();
+    }
+    result = ssum;
+  } else {
+    double acc = 0.0;
+    for (int i = gl; i < N; i += G) {
+      const double d = a.dmode ? a.pred[i] + a.resid[idx_row[i]] : a.D[i];
+      const double r = d - ic - dtab[a.tid[i]];
+      acc = acc + (r * r + pen);
+    }
+    result = group_sum<G>(acc);
+  }
+  if (valid) {
+    if (gl == 0) {
+      a.cost[m] = result;
+      if (a.puu) a.puu[m] = puu;
+    }
+    if (a.dt)
+      for (int i = gl; i < N; i += G) a.dt[(size_t)m * N + i] = dtab[a.tid[i]];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bootstrap index generation (src/boot_model.rs:43-48): idx[(w*B + b)*N + i] in [0,N).  One Philox
+// call yields the indices of rows 4q..4q+3 of one bootstrap.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void abn_gen_idx_kernel(uint32_t* idx, int N, int B, int W, uint64_t seed,
+                                                          uint32_t window_offset, uint32_t boot_offset) {
+  const int Q = (N + 3) / 4;
+  const long long total = (long long)W * B * Q;
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const int q = (int)(t % Q);
+    const long long wb = t / Q;
+    const int b = (int)(wb % B);
+    const int w = (int)(wb / B);
+    uint32_t r[4];
+    philox4x32_10((uint32_t)q, boot_offset + (uint32_t)b, window_offset + (uint32_t)w, kTagIdx, k0, k1, r);
+    uint32_t* row = idx + (size_t)wb * (size_t)N;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * q + e;
+      if (i < N) row[i] = index_from(r[e], (uint32_t)N);
+    }
+  }
+}
+
+}  // namespace abn

@@ -1,0 +1,170 @@
+/*
+ * abneutral.h — C-ABI of the MI355X-native ABneutral hot path (libabneutral_hip.so).
+ *
+ * Drop-in boundary for alphabeta-rs v0.2.1 (citations relative to the reference tree).  The reference
+ * has no FFI layer; the seams this library sits behind are Rust-level:
+ *   (1) `impl CostFunction for Problem`          src/structs.rs:191-217      -> abn_cost_batch
+ *   (2) `ab_neutral::run`                        src/ab_neutral.rs:13-20     -> abn_ab_neutral_run
+ *   (3) `boot_model::run`                        src/boot_model.rs:17-28     -> abn_boot_model_run
+ *   (4) the serial window loop of `metaprofile`  src/cli/metaprofile.rs:50-72 -> abn_plan_* (batched)
+ * INTEGRATION.md shows the `extern "C"` block + safe wrappers a maintainer would add on the Rust side.
+ *
+ * Conventions: plain pointers and sizes, all f64 unless noted, row-major, caller owns every buffer it
+ * passes; the library owns device memory behind the opaque handles.  No exceptions cross the ABI and
+ * nothing aborts: every entry point returns an abn_status (0 = ok).  A handle is thread-compatible
+ * (one thread at a time); there is no hidden global state.
+ *
+ * There is NO CPU fallback: without a HIP device every compute entry point returns ABN_ERR_NO_DEVICE.
+ */
+#ifndef ABNEUTRAL_H
+#define ABNEUTRAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ABN_VERSION_MAJOR 0
+#define ABN_VERSION_MINOR 1
+
+typedef enum abn_status {
+  ABN_OK = 0,
+  ABN_ERR_INVALID_ARG = 1,   /* null pointer, non-positive size, unsupported option value            */
+  ABN_ERR_BAD_PEDIGREE = 2,  /* a generation outside 0..127 after the `as i8` cast, or t1/t2 < t0      */
+  ABN_ERR_NO_DEVICE = 3,     /* no usable HIP device (the product path never falls back to the CPU)    */
+  ABN_ERR_HIP = 4,           /* a HIP runtime call failed; see abn_last_error()                        */
+  ABN_ERR_NO_FINITE_FIT = 5, /* every start of a window ended non-finite (reference: panic, :28,:100)  */
+  ABN_ERR_STATE = 6          /* plan used out of order (e.g. run before set_windows)                   */
+} abn_status;
+
+/* per-fit termination status, written in fit order (no push-under-lock as in src/ab_neutral.rs:74) */
+#define ABN_FIT_CONVERGED 0  /* SD of the 5 simplex costs < sd_tolerance (argmin SolverConverged)     */
+#define ABN_FIT_MAX_ITERS 1  /* iteration budget reached (argmin MaxItersReached)                     */
+#define ABN_FIT_NONFINITE 2  /* no finite best parameter vector (reference: `.unwrap()` panic)        */
+#define ABN_FIT_TARGET 3     /* best cost <= -inf (argmin TargetCostReached with default target)      */
+
+typedef struct abn_ctx abn_ctx;
+typedef struct abn_plan abn_plan;
+
+typedef struct abn_options {
+  uint64_t seed;                        /* Philox4x32-10 key (reference: unseeded thread_rng)           */
+  int32_t lanes_per_chain;              /* 0 = auto; 8, 16, 32 or 64 lanes of a wavefront per chain    */
+  int32_t strict_order;                 /* abn_cost_batch: 1 = serial row-order sum (reference order)  */
+  int32_t shrink_on_failed_contraction; /* 0 = argmin 0.8.1 behaviour; 1 = textbook Nelder-Mead        */
+  int32_t max_iters_start;              /* 10000, src/ab_neutral.rs:62                                 */
+  int32_t max_iters_boot;               /* 1000,  src/boot_model.rs:81                                 */
+  int32_t reserved0;
+  double sd_tolerance;                  /* f64::EPSILON (argmin default, never overridden)             */
+} abn_options;
+
+typedef struct abn_fit_info {
+  double best_cost; /* argmin state.best_cost (includes the equilibrium penalty)                        */
+  int32_t iters;    /* next_iter() calls                                                                */
+  int32_t evals;    /* cost() calls                                                                     */
+  int32_t status;   /* ABN_FIT_*                                                                        */
+  int32_t lanes;    /* lanes per chain the kernel used (defines the residual reduction tree)            */
+} abn_fit_info;
+
+/* ------------------------------------------------------------------ context */
+void abn_default_options(abn_options* opts);
+int abn_device_count(int* count);
+/* stream == NULL: the context creates (and owns) its own non-blocking HIP stream; otherwise the given
+ * hipStream_t is borrowed (e.g. torch.cuda.current_stream().cuda_stream). */
+int abn_init(int device_ordinal, void* stream, abn_ctx** ctx);
+int abn_shutdown(abn_ctx* ctx);
+const char* abn_last_error(const abn_ctx* ctx);
+const char* abn_status_string(int status);
+int abn_version(void);
+
+/* ------------------------------------------------------------------ (1) cost function
+ * Replaces `Problem::cost` (src/structs.rs:194-216) + `divergence()` (src/divergence.rs:33-94) for M
+ * candidates at once.  pedigree: N x 4 rows (t0,t1,t2,D) exactly as `Pedigree` (src/pedigree.rs:44-45).
+ * Observed divergences: column 3 of the pedigree, or, when idx != NULL, the residual bootstrap
+ * D*_i = pred[i] + resid[idx[cand_to_boot[m]*N + i]] (src/boot_model.rs:50-57).
+ * Outputs: cost[M]; optional dt1t2[M x N] and p_uu_inf[M] (struct Divergence, src/divergence.rs:10-14). */
+int abn_cost_batch(abn_ctx* ctx, const abn_options* opts, const double* pedigree, int32_t n_rows,
+                   double p_uu0, double eqp, double eqp_weight, const double* candidates, int64_t m,
+                   const double* pred, const double* resid, const uint32_t* idx,
+                   const uint32_t* cand_to_boot, int64_t n_boot_rows, double* cost, double* dt1t2,
+                   double* p_uu_inf);
+
+/* ------------------------------------------------------------------ Nelder-Mead fits
+ * Replaces `Executor::new(problem, NelderMead::new(simplex)).max_iters(k).run()` (src/ab_neutral.rs:49-64,
+ * src/boot_model.rs:69-84) for F independent fits, one per simplex0[f] (5 vertices x 4).
+ * dobs_rows: NULL (every fit uses pedigree column 3) or F x N observed divergences.
+ * Outputs in fit order: best[F x 4] (argmin best_param), info[F]. */
+int abn_fit_batch(abn_ctx* ctx, const abn_options* opts, const double* pedigree, int32_t n_rows,
+                  double p_uu0, double eqp, double eqp_weight, const double* simplex0, int64_t f,
+                  const double* dobs_rows, int32_t max_iters, double* best, abn_fit_info* info);
+
+/* ------------------------------------------------------------------ deterministic inputs
+ * Model::new x5 per start (src/structs.rs:78-96): simplex0[S x 5 x 4] for `window`. Host arithmetic. */
+int abn_gen_start_simplices(uint64_t seed, uint32_t window, int32_t n_starts, double max_divergence,
+                            double* simplex0);
+/* [params, vary() x4] (src/boot_model.rs:69-75, src/structs.rs:100-128) for boots [b0, b0+nb) */
+int abn_gen_boot_simplices(uint64_t seed, uint32_t window, uint32_t b0, int64_t nb,
+                           const double params[4], double* simplex0);
+/* residual-bootstrap indices (src/boot_model.rs:43-48) idx[nb x N], generated ON DEVICE, copied back */
+int abn_gen_boot_indices(abn_ctx* ctx, uint64_t seed, uint32_t window, uint32_t b0, int64_t nb,
+                         int32_t n_rows, uint32_t* idx);
+
+/* ------------------------------------------------------------------ (2) ab_neutral::run
+ * src/ab_neutral.rs:13-142: n_starts random-start fits (start simplices from opts->seed), arg-min by
+ * pure LSE (:83-101), predicted divergence (:123-129) and residuals (:131-135).
+ * Outputs: model[4], pred[N], resid[N]; optional all_models[S x 4], info[S], lse[S]. */
+int abn_ab_neutral_run(abn_ctx* ctx, const abn_options* opts, const double* pedigree, int32_t n_rows,
+                       double p0uu, double eqp, double eqp_weight, int32_t n_starts, double* model,
+                       double* pred, double* resid, double* all_models, abn_fit_info* info,
+                       double* lse);
+
+/* ------------------------------------------------------------------ (3) boot_model::run
+ * src/boot_model.rs:17-115 without the PNG (:105-109): n_boot residual-bootstrap refits.
+ * raw[n_boot x 7] = [alpha,beta,weight,intercept,PrMM,PrUM,PrUU] rows (RawAnalysis, src/analysis.rs:12),
+ * row b = bootstrap b (the reference's row order is thread-schedule dependent).  info optional. */
+int abn_boot_model_run(abn_ctx* ctx, const abn_options* opts, const double* pedigree, int32_t n_rows,
+                       const double* model, const double* pred, const double* resid, double p0uu,
+                       double eqp, double eqp_weight, int32_t n_boot, double* raw,
+                       abn_fit_info* info);
+
+/* src/analysis.rs:50-98 on the host: out[32] = mean[8], sd[8], ci_lo[8], ci_hi[8] in the order
+ * alpha, beta, beta/alpha, weight, intercept, pr_mm, pr_um, pr_uu (struct Analysis, :15-47). */
+int abn_analyze(const double* raw, int64_t n_boot, double* out32);
+
+/* ------------------------------------------------------------------ (4) batched, device-resident plan
+ * One pedigree topology (t0,t1,t2 of N rows), W windows that differ in D / p0uu (the metaprofile loop,
+ * src/cli/metaprofile.rs:50-72, where every window shares nodelist/edgelist), S starts and B bootstraps
+ * per window.  boot_offset / window_offset place this plan's shard in the global (window, bootstrap)
+ * index space so that results do not depend on how the job is sharded over GPUs. */
+int abn_plan_create(abn_ctx* ctx, const abn_options* opts, const double* generations /* N x 3 */,
+                    int32_t n_rows, int32_t n_windows, int32_t n_starts, int32_t n_boot,
+                    uint32_t window_offset, uint32_t boot_offset, abn_plan** plan);
+int abn_plan_destroy(abn_plan* plan);
+/* D[W x N], p0uu[W]; eqp = p0uu and eqp_weight = 1 as src/alphabeta.rs:33-54 unless eqp/eqp_weight
+ * are non-NULL ([W] each).  Also draws the start simplices and generates the bootstrap index buffer
+ * idx[W x B x N] (u32) in HBM on the device. */
+int abn_plan_set_windows(abn_plan* plan, const double* d_obs, const double* p0uu, const double* eqp,
+                         const double* eqp_weight);
+/* enqueue phase A (starts) -> select -> phase B (bootstraps) on the context's stream; asynchronous */
+int abn_plan_run(abn_plan* plan);
+int abn_plan_run_phase(abn_plan* plan, int32_t phase /* 0 = A+select, 1 = B */);
+int abn_plan_sync(abn_plan* plan);
+/* HIP-event time of the most recent launch of each kernel, in milliseconds (fit A, select, fit B) */
+int abn_plan_kernel_ms(abn_plan* plan, double* ms3);
+/* device pointer of raw[W x B x 7] (for an RCCL gather by the caller) and optional rebinding to a
+ * caller-owned device buffer of the same size */
+int abn_plan_raw_device_ptr(abn_plan* plan, void** dev_ptr);
+int abn_plan_bind_raw(abn_plan* plan, void* dev_ptr);
+/* copy results to the host; any pointer may be NULL.  models[W x 4], pred[W x N], resid[W x N],
+ * raw[W x B x 7], info_a[W x S], info_b[W x B], best_start[W] (int32, -1 = ABN_ERR_NO_FINITE_FIT) */
+int abn_plan_download(abn_plan* plan, double* models, double* pred, double* resid, double* raw,
+                      abn_fit_info* info_a, abn_fit_info* info_b, int32_t* best_start);
+/* sums over all fits of the last run (for evals/s): out[0] = fits, out[1] = evals, out[2] = iters */
+int abn_plan_counters(abn_plan* plan, int64_t* out3);
+/* number of bytes of device memory the plan holds (index buffer included) */
+int abn_plan_device_bytes(abn_plan* plan, int64_t* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ABNEUTRAL_H */

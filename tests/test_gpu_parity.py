@@ -1,0 +1,302 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle and the reference's golden vectors.
+
+Floating-point bar: the north star asks for 1e-6 on (alpha, beta, weight, predicted divergence).  The
+tests hold the kernel to a much tighter bar — BIT-EXACT equality with the oracle on identical inputs
+(same start simplices, same bootstrap indices, same reduction tree) — because Nelder-Mead is chaotic
+under 1-ulp cost differences; wherever a tolerance is used instead it is written in the test.
+"""
+import numpy as np
+import pytest
+
+from conftest import COST_KNOWN_ANSWER, MODEL_DEFAULT
+
+pytestmark = pytest.mark.gpu
+
+LANES = (8, 16, 32, 64)
+
+
+def synthetic_pedigree(rng, n, tmax, frac_t0=0.3):
+    """random valid (t0,t1,t2,D) rows: t0 <= t1,t2 <= tmax"""
+    t0 = np.where(rng.random(n) < frac_t0, rng.integers(0, max(1, tmax // 2), n), 0)
+    t1 = t0 + rng.integers(0, tmax - t0 + 1)
+    t2 = t0 + rng.integers(0, tmax - t0 + 1)
+    d = np.abs(rng.normal(0.01, 0.004, n))
+    return np.stack([t0, t1, t2, d], axis=1).astype(np.float64)
+
+
+# ------------------------------------------------------------------------------------------------ cost
+def test_cost_known_answer_strict_bit_exact(abn, gpu_ctx, golden):
+    """src/structs.rs:225-240 on the GPU: serial row order -> 0.0006700888539608879 exactly."""
+    o = abn.default_options(strict_order=1)
+    c = gpu_ctx.cost_batch(golden["pedigree"], 0.75, 0.5, 0.7, MODEL_DEFAULT[None, :], options=o)
+    assert c[0] == COST_KNOWN_ANSWER
+
+
+def test_divergence_same_as_r(abn, gpu_ctx, golden, oracle):
+    """src/divergence.rs:138-161 on the GPU, and bit-equality of dt1t2 / p_uu with the oracle."""
+    x = np.array([[3.974271e-09, 1.519045e-07, 0.06892953, 0.0]])
+    cost, dt, puu = gpu_ctx.cost_batch(golden["pedigree"], 0.75, 0.5, 0.7, x, want_dt=True, want_puu=True)
+    r = golden["divergence"]
+    assert np.max(np.abs(dt[0] - r)) < 1e-15          # reference tolerance: 1e-4 (src/macros.rs:15)
+    want_dt, want_puu = oracle.divergence(golden["pedigree"], 0.25, 0.75, *x[0, :3])
+    assert np.array_equal(dt[0], want_dt)
+    assert puu[0] == want_puu
+
+
+@pytest.mark.parametrize("lanes", LANES)
+def test_cost_batch_matches_oracle_tree_order(abn, gpu_ctx, golden, oracle, lanes):
+    rng = np.random.default_rng(100 + lanes)
+    for ped, p0 in ((golden["pedigree"], 0.75), (golden["sparse"], golden["r_p0uu"]),
+                    (golden["generated"], golden["p0uu_generated"]), (synthetic_pedigree(rng, 517, 40), 0.8)):
+        m = 33
+        cand = np.stack([10 ** rng.uniform(-9, -2, m), 10 ** rng.uniform(-9, -2, m), rng.uniform(0, 0.1, m),
+                         rng.uniform(0, ped[:, 3].max(), m)], axis=1)
+        cand[0] = [-1e-5, 2e-5, 0.5, 0.0]       # negative rate: still finite arithmetic
+        o = abn.default_options(lanes_per_chain=lanes)
+        got, dt, puu = gpu_ctx.cost_batch(ped, p0, 0.5, 0.7, cand, options=o, want_dt=True, want_puu=True)
+        want = np.array([oracle.cost(ped, p0, 0.5, 0.7, x, lanes=lanes) for x in cand])
+        assert np.array_equal(got, want)
+        strict = gpu_ctx.cost_batch(ped, p0, 0.5, 0.7, cand, options=abn.default_options(strict_order=1))
+        want_strict = np.array([oracle.cost(ped, p0, 0.5, 0.7, x, lanes=1, table=False) for x in cand])
+        assert np.array_equal(strict, want_strict)
+        for k in (0, 1, m - 1):
+            wdt, wp = oracle.divergence(ped, 1 - p0, p0, *cand[k, :3])
+            assert np.array_equal(dt[k], wdt) and puu[k] == wp
+
+
+def test_cost_batch_nonfinite_candidates(abn, gpu_ctx, golden, oracle):
+    ped = golden["sparse"]
+    cand = np.array([[0.0, 0.0, 0.03, 0.0],          # alpha+beta = 0 -> 0/0 in p_uu_est
+                     [np.inf, 1e-4, 0.03, 0.0], [np.nan, 1e-4, 0.03, 0.0], [1e-4, 1e-4, np.inf, 0.0]])
+    got = gpu_ctx.cost_batch(ped, 0.9, 0.9, 1.0, cand, options=abn.default_options(lanes_per_chain=16))
+    want = np.array([oracle.cost(ped, 0.9, 0.9, 1.0, x, lanes=16) for x in cand])
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)])
+
+
+def test_cost_batch_bootstrap_observations(abn, gpu_ctx, golden, oracle):
+    ped, p0 = golden["sparse"], golden["r_p0uu"]
+    n = ped.shape[0]
+    rng = np.random.default_rng(5)
+    pred, resid = rng.normal(0.005, 0.001, n), rng.normal(0, 1e-3, n)
+    idx = np.stack([oracle.boot_indices(42, 0, b, n) for b in range(6)])
+    cand = np.tile(np.array([[5.8e-05, 6.5e-03, 0.03, 6e-05]]), (9, 1)) * rng.uniform(0.9, 1.1, (9, 4))
+    c2b = np.array([0, 1, 2, 3, 4, 5, 5, 0, 3], dtype=np.uint32)
+    got = gpu_ctx.cost_batch(ped, p0, p0, 1.0, cand, pred=pred, resid=resid, idx=idx, cand_to_boot=c2b,
+                             options=abn.default_options(lanes_per_chain=16))
+    want = np.array([oracle.cost(ped, p0, p0, 1.0, cand[k], dobs=pred + resid[idx[c2b[k]]], lanes=16)
+                     for k in range(9)])
+    assert np.array_equal(got, want)
+
+
+def test_bad_pedigree_is_rejected(abn, gpu_ctx):
+    for rows in ([[2.0, 1.0, 3.0, 0.1]], [[-1.0, 1.0, 3.0, 0.1]]):
+        with pytest.raises(abn.AbnError) as e:
+            gpu_ctx.cost_batch(np.array(rows), 0.75, 0.5, 0.7, MODEL_DEFAULT[None, :])
+        assert e.value.status == 2
+    # generations saturate at 127 like Rust's `as i8` (src/divergence.rs:52)
+    sat = np.array([[0.0, 500.0, 127.0, 0.1]])
+    a = gpu_ctx.cost_batch(sat, 0.75, 0.5, 0.7, MODEL_DEFAULT[None, :])
+    b = gpu_ctx.cost_batch(np.array([[0.0, 127.0, 127.0, 0.1]]), 0.75, 0.5, 0.7, MODEL_DEFAULT[None, :])
+    assert a[0] == b[0]
+
+
+# ------------------------------------------------------------------------------------------------ inputs
+def test_bootstrap_indices_bit_exact(abn, gpu_ctx, oracle):
+    for n in (6, 78, 105, 351, 1023):
+        got = gpu_ctx.gen_boot_indices(20260101, 7, 1000, 5, n)
+        want = np.stack([oracle.boot_indices(20260101, 7, 1000 + b, n) for b in range(5)])
+        assert got.dtype == np.uint32 and np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------ fits
+def _assert_fits_equal(best, info, want):
+    assert np.array_equal(info["status"], want["status"])
+    assert np.array_equal(info["iters"], want["iters"])
+    assert np.array_equal(info["evals"], want["evals"])
+    ok = want["status"] != 2
+    assert np.array_equal(best[ok], want["best"][ok])
+    assert np.array_equal(info["best_cost"][ok], want["best_cost"][ok])
+
+
+@pytest.mark.parametrize("lanes", LANES)
+@pytest.mark.parametrize("variant", (0, 1))
+def test_fit_batch_trajectories_bit_exact(abn, gpu_ctx, golden, oracle, lanes, variant):
+    """Identical start simplices -> identical Nelder-Mead trajectory (iterations, evaluations, best
+    parameters and cost all bit-equal to the oracle run with the same reduction tree)."""
+    cases = (("sparse", golden["sparse"], golden["r_p0uu"], 24, 3000),
+             ("generated", golden["generated"], golden["p0uu_generated"], 24, 1500),
+             ("golden351", golden["pedigree"], 0.75, 8, 400))
+    for name, ped, p0, f, iters in cases:
+        s0 = abn.gen_start_simplices(11 + lanes, 0, f, ped[:, 3].max())
+        o = abn.default_options(lanes_per_chain=lanes, shrink_on_failed_contraction=variant)
+        best, info = gpu_ctx.fit_batch(ped, p0, p0, 1.0, s0, iters, options=o)
+        want = oracle.fit_batch(ped, p0, p0, 1.0, s0, iters, shrink_variant=variant, lanes=lanes)
+        assert np.all(info["lanes"] == lanes)
+        _assert_fits_equal(best, info, want)
+
+
+def test_fit_batch_stream_mode_large_pedigree(abn, gpu_ctx, oracle):
+    """N > 8 rows per lane: the kernel re-streams rows every evaluation (stream mode)."""
+    rng = np.random.default_rng(77)
+    ped = synthetic_pedigree(rng, 700, 12)
+    true = np.array([1e-4, 5e-4, 0.03, 1e-3])
+    dt, _ = oracle.divergence(ped, 0.25, 0.75, *true[:3], table=True)
+    ped[:, 3] = np.maximum(true[3] + dt + rng.normal(0, 2e-4, 700), 0)
+    s0 = abn.gen_start_simplices(5, 0, 6, ped[:, 3].max())
+    for lanes in (16, 64):
+        o = abn.default_options(lanes_per_chain=lanes)
+        best, info = gpu_ctx.fit_batch(ped, 0.75, 0.75, 1.0, s0, 300, options=o)
+        want = oracle.fit_batch(ped, 0.75, 0.75, 1.0, s0, 300, lanes=lanes)
+        _assert_fits_equal(best, info, want)
+
+
+def test_fit_batch_per_fit_observations(abn, gpu_ctx, golden, oracle):
+    ped, p0 = golden["sparse"], golden["r_p0uu"]
+    n = ped.shape[0]
+    rng = np.random.default_rng(9)
+    f = 10
+    dobs = np.abs(ped[:, 3][None, :] + rng.normal(0, 2e-4, (f, n)))
+    s0 = abn.gen_boot_simplices(3, 0, 0, f, np.array([5.8e-05, 6.5e-03, 0.03, 6e-05]))
+    best, info = gpu_ctx.fit_batch(ped, p0, p0, 1.0, s0, 1000, dobs_rows=dobs,
+                                   options=abn.default_options(lanes_per_chain=16))
+    want = oracle.fit_batch(ped, p0, p0, 1.0, s0, 1000, dobs_rows=dobs, lanes=16)
+    _assert_fits_equal(best, info, want)
+
+
+def test_fit_nonfinite_start_reports_status(abn, gpu_ctx, golden, oracle):
+    ped, p0 = golden["generated"], golden["p0uu_generated"]
+    s0 = abn.gen_start_simplices(1, 0, 3, ped[:, 3].max())
+    s0[1, :, 0] = np.nan                        # every vertex NaN -> never a finite best
+    s0[2, 2, 1] = np.nan                        # one NaN vertex
+    o = abn.default_options(lanes_per_chain=8)
+    best, info = gpu_ctx.fit_batch(ped, p0, p0, 1.0, s0, 200, options=o)
+    want = oracle.fit_batch(ped, p0, p0, 1.0, s0, 200, lanes=8)
+    assert info["status"][1] == abn.FIT_NONFINITE
+    _assert_fits_equal(best, info, want)
+
+
+# ------------------------------------------------------------------------------------------------ runs
+def _oracle_ab_neutral(oracle, abn, ped, p0, eqp, ew, n_starts, seed, lanes, max_iters=10000):
+    s0 = abn.gen_start_simplices(seed, 0, n_starts, ped[:, 3].max())
+    fits = oracle.fit_batch(ped, p0, eqp, ew, s0, max_iters, lanes=lanes)
+    k, model, pred, resid, lse = oracle.select_best(ped, p0, fits["best"])
+    return k, model, pred, resid, lse, fits
+
+
+@pytest.mark.parametrize("case", ("generated", "sparse"))
+def test_ab_neutral_and_boot_model_match_oracle(abn, gpu_ctx, golden, oracle, case):
+    """src/ab_neutral.rs:13-142 then src/boot_model.rs:17-115, eqp = p0uu, eqp_weight = 1
+    (src/alphabeta.rs:33-54): fitted model, predicted divergence, residuals and the bootstrap table."""
+    ped = golden[case]
+    p0 = golden["p0uu_generated"] if case == "generated" else golden["r_p0uu"]
+    seed, n_starts, n_boot = 20260101, 10, 64
+    o = abn.default_options(seed=seed)
+    model, pred, resid, extra = gpu_ctx.ab_neutral_run(ped, p0, p0, 1.0, n_starts, options=o)
+    lanes = int(extra["info"]["lanes"][0])
+    k, wmodel, wpred, wresid, wlse, wfits = _oracle_ab_neutral(oracle, abn, ped, p0, p0, 1.0, n_starts, seed, lanes)
+    _assert_fits_equal(extra["models"], extra["info"], wfits)
+    assert np.array_equal(extra["lse"], wlse)
+    assert np.array_equal(model, wmodel)                 # north-star bar: 1e-6; held: bit-exact
+    assert np.array_equal(pred, wpred) and np.array_equal(resid, wresid)
+    assert np.max(np.abs(pred - wpred)) <= 1e-6          # the stated tolerance, trivially met
+    raw, info = gpu_ctx.boot_model_run(ped, model, pred, resid, p0, p0, 1.0, n_boot, options=o)
+    wraw, wres = oracle.boot_model(ped, wmodel, wpred, wresid, p0, p0, 1.0, seed, 0, 0, n_boot, lanes=lanes)
+    assert np.array_equal(info["iters"], wres["iters"]) and np.array_equal(info["evals"], wres["evals"])
+    assert np.array_equal(raw, wraw)
+
+
+def test_plan_multi_window_matches_per_window_runs(abn, gpu_ctx, golden, oracle):
+    """The batched plan (metaprofile shape: W windows, one topology) equals W independent oracle runs,
+    and does not depend on how bootstraps are sharded (boot_offset)."""
+    ped = golden["sparse"].copy()
+    n = ped.shape[0]
+    rng = np.random.default_rng(21)
+    W, S, B, seed = 3, 4, 12, 77
+    D = np.abs(ped[:, 3][None, :] * rng.uniform(0.8, 1.2, (W, 1)) + rng.normal(0, 1e-4, (W, n)))
+    p0 = np.array([0.99, 0.985, 0.992])
+    o = abn.default_options(seed=seed, lanes_per_chain=16)
+    plan = abn.Plan(gpu_ctx, ped[:, :3], W, S, B, options=o)
+    plan.set_windows(D, p0)
+    plan.run()
+    out = plan.download()
+    cnt = plan.counters()
+    assert cnt["fits"] == W * (S + B)
+    assert cnt["evals"] == out["info_a"]["evals"].sum() + out["info_b"]["evals"].sum()
+    for w in range(W):
+        pw = ped.copy()
+        pw[:, 3] = D[w]
+        s0 = abn.gen_start_simplices(seed, w, S, D[w].max())
+        fits = oracle.fit_batch(pw, p0[w], p0[w], 1.0, s0, 10000, lanes=16)
+        k, model, pred, resid, _ = oracle.select_best(pw, p0[w], fits["best"])
+        assert out["best_start"][w] == k
+        assert np.array_equal(out["models"][w], model)
+        assert np.array_equal(out["pred"][w], pred) and np.array_equal(out["resid"][w], resid)
+        wraw, _ = oracle.boot_model(pw, model, pred, resid, p0[w], p0[w], 1.0, seed, w, 0, B, lanes=16)
+        assert np.array_equal(out["raw"][w], wraw)
+    # shard of bootstraps [5, 12) of window 1 only
+    pw = ped.copy()
+    plan2 = abn.Plan(gpu_ctx, ped[:, :3], 1, S, 7, window_offset=1, boot_offset=5, options=o)
+    plan2.set_windows(D[1:2], p0[1:2])
+    plan2.run()
+    out2 = plan2.download()
+    assert np.array_equal(out2["models"][0], out["models"][1])
+    assert np.array_equal(out2["raw"][0], out["raw"][1, 5:12])
+    ms = plan.kernel_ms()
+    assert ms["fit_boot"] > 0 and ms["fit_starts"] > 0
+    plan.close()
+    plan2.close()
+
+
+def test_device_sqrt_and_division_are_correctly_rounded(abn, gpu_ctx, oracle):
+    """The termination test uses sqrt, the cost uses one division: bootstrap rows (est_mm/um/uu) from
+    the kernel must equal the host formulas bit for bit."""
+    ped = np.array([[0.0, 1.0, 2.0, 0.01], [0.0, 2.0, 3.0, 0.02], [1.0, 2.0, 2.0, 0.015], [0.0, 3.0, 3.0, 0.03]])
+    model = np.array([3.1e-4, 7.7e-4, 0.031, 1.1e-3])
+    pred = np.array([0.011, 0.019, 0.016, 0.029])
+    resid = ped[:, 3] - pred
+    raw, info = gpu_ctx.boot_model_run(ped, model, pred, resid, 0.8, 0.8, 1.0, 50,
+                                       options=abn.default_options(lanes_per_chain=8))
+    for row in raw:
+        assert np.array_equal(row, oracle.bootstrap_row(row[:4]))
+
+
+# ------------------------------------------------------------------------------------------------ properties
+def test_full_size_properties_c3(abn, gpu_ctx, oracle):
+    """BASELINE config C3 (105 rows, 10000 bootstraps) at full size through size-independent properties:
+    determinism (two runs bit-identical), shard-independence, internal consistency of every row, and a
+    sampled subset bit-equal to the oracle."""
+    from alphabeta_rs_amd import synthetic
+
+    ped, p0 = synthetic.c3_pedigree()
+    n = ped.shape[0]
+    B = 10000
+    o = abn.default_options(seed=20260101)
+    plan = abn.Plan(gpu_ctx, ped[:, :3], 1, 10, B, options=o)
+    plan.set_windows(ped[:, 3][None, :], np.array([p0]))
+    plan.run()
+    a = plan.download()
+    plan.run()
+    b = plan.download()
+    assert np.array_equal(a["raw"], b["raw"]) and np.array_equal(a["models"], b["models"])   # idempotence
+    raw = a["raw"][0]
+    assert np.all(np.isfinite(raw))
+    assert np.all(a["info_b"]["status"] != abn.FIT_NONFINITE)
+    assert np.all(a["info_b"]["iters"] <= 1000) and np.all(a["info_b"]["evals"] >= 5)
+    # every row's equilibrium columns follow src/structs.rs:146-159 from its own (alpha, beta)
+    for row in raw[:: B // 50]:
+        assert np.array_equal(row, oracle.bootstrap_row(row[:4]))
+    # pred + resid reproduces the observations
+    assert np.allclose(a["pred"][0] + a["resid"][0], ped[:, 3], rtol=0, atol=1e-17)
+    # sampled bootstraps against the oracle (bit-exact)
+    lanes = int(a["info_b"]["lanes"][0, 0])
+    for b0 in (0, 4321, 9990):
+        wraw, wres = oracle.boot_model(ped, a["models"][0], a["pred"][0], a["resid"][0], p0, p0, 1.0, 20260101, 0,
+                                       b0, 10, lanes=lanes)
+        assert np.array_equal(raw[b0:b0 + 10], wraw)
+        assert np.array_equal(a["info_b"]["evals"][0, b0:b0 + 10], wres["evals"])
+    # the fitted rates recover the synthetic truth to within a factor of two (one noise realisation)
+    an = abn.analyze(raw)
+    assert 0.5 < an[0, 0] / synthetic.TRUE_PARAMS[0] < 2.0
+    assert 0.5 < an[0, 1] / synthetic.TRUE_PARAMS[1] < 2.0
+    plan.close()
