@@ -135,12 +135,17 @@ static int upload_topology(abn_ctx* c, const Topology& t, DevTopology& d) {
 // ------------------------------------------------------------------------------------------------
 constexpr size_t kMaxDynLds = 64 * 1024;
 
-static int pick_lanes(int n, int requested) {
+// Lanes of a wavefront per chain.  Auto: by pedigree rows, then widened until the workgroup's LDS
+// (64/G chains x chain_stride doubles) leaves room for >= 8 workgroups per CU (160 KiB LDS).
+constexpr size_t kLdsTargetPerBlock = 20 * 1024;
+static int pick_lanes(int n, int requested, int chain_stride) {
   if (requested == 8 || requested == 16 || requested == 32 || requested == 64) return requested;
-  if (n <= 32) return 8;
-  if (n <= 128) return 16;
-  if (n <= 256) return 32;
-  return 64;
+  int g = 64;
+  if (n <= 32) g = 8;
+  else if (n <= 128) g = 16;
+  else if (n <= 256) g = 32;
+  while (g < 64 && (size_t)(kWave / g) * (size_t)chain_stride * sizeof(double) > kLdsTargetPerBlock) g *= 2;
+  return g;
 }
 static int pick_rmax(int n, int lanes) {
   const int per = (n + lanes - 1) / lanes;
@@ -386,7 +391,7 @@ extern "C" int abn_cost_batch(abn_ctx* c, const abn_options* opts, const double*
   if (dt1t2) HIPCHK(c, ddt.alloc((size_t)m * (size_t)N));
   if (p_uu_inf) HIPCHK(c, dpuu.alloc((size_t)m));
 
-  const int lanes = o.strict_order ? 64 : pick_lanes(N, o.lanes_per_chain);
+  const int lanes = o.strict_order ? 64 : pick_lanes(N, o.lanes_per_chain, t.chain_stride);
   const int ng = kWave / lanes;
   CostArgs a{};
   a.tri = dt.tri.p;
@@ -501,7 +506,7 @@ extern "C" int abn_fit_batch(abn_ctx* c, const abn_options* opts, const double* 
   a.best = dbest.p;
   a.info = dinfo.p;
   a.raw = nullptr;
-  const int lanes = pick_lanes(N, o.lanes_per_chain);
+  const int lanes = pick_lanes(N, o.lanes_per_chain, t.chain_stride);
   rc = launch_fit(c, a, lanes);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(best, dbest.p, dbest.bytes(), hipMemcpyDeviceToHost, c->stream));
@@ -563,7 +568,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
     delete p;
     return set_err(c, rc, abn_status_string(rc));
   }
-  p->lanes = pick_lanes(n_rows, p->opt.lanes_per_chain);
+  p->lanes = pick_lanes(n_rows, p->opt.lanes_per_chain, p->topo.chain_stride);
   if ((size_t)(kWave / p->lanes) * p->topo.chain_stride * sizeof(double) > kMaxDynLds ||
       ((size_t)p->topo.chain_stride + kSelChunk) * sizeof(double) > kMaxDynLds) {
     delete p;
