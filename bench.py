@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py — ABneutral model fits/sec on MI355X (BASELINE.json metric), one JSON line on rank 0.
+
+A "step" is one pass of the hot path over one batch: phase A (S random-start Nelder-Mead fits per
+window, src/ab_neutral.rs:37-78), selection (src/ab_neutral.rs:83-135), phase B (B residual-bootstrap
+refits per window, src/boot_model.rs:41-100) and, for N > 1 GPUs, the RCCL all-gather of the bootstrap
+tables.  Inputs (pedigree, observations, start simplices, bootstrap index buffer) are resident in HBM
+before the timed region.  Each rank owns the windows [rank*Wr, (rank+1)*Wr) (weak scaling: per-GPU work
+is fixed) and there is no data-path collective other than the final gather.
+
+Workloads:  c3 (default) synthetic 100-edge / 8-generation pedigree, N=105 rows, 10 starts
++ 10000 bootstraps per window, one window per GPU;  c2 bundled pedigree (6 rows) x 1000 bootstraps;
+c4 the C3 topology, 25 windows x 1000 bootstraps per GPU (= 200 windows over 8 GPUs);  g351 the
+reference's golden pedigree (351 rows, T=32) x 1000 bootstraps.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+
+
+def make_workload(name: str, rank: int, world: int):
+    """returns dict(gens Nx3, D [W,N], p0uu [W], S, B, label)"""
+    from alphabeta_rs_amd import synthetic
+
+    if name == "c3":
+        gens, D, p0, _ = synthetic.c4_windows(1, window_offset=rank)
+        if world == 1:  # exactly BASELINE C3
+            ped, p = synthetic.c3_pedigree()
+            gens, D, p0 = ped[:, :3], ped[:, 3][None, :], np.array([p])
+        return dict(gens=gens, D=D, p0=p0, S=10, B=10000, wr=1,
+                    label="C3: synthetic 100-edge/8-generation pedigree (N=105 rows, T=8, K=47 distinct triples), "
+                          "10 starts + 10000 bootstraps per window, 1 window per GPU")
+    if name == "c4":
+        gens, D, p0, _ = synthetic.c4_windows(25, window_offset=25 * rank)
+        return dict(gens=gens, D=D, p0=p0, S=10, B=1000, wr=25,
+                    label="C4 shard: C3 topology, 25 windows x (10 starts + 1000 bootstraps) per GPU "
+                          "(200 windows over 8 GPUs)")
+    if name in ("c2", "g351"):
+        # fixtures are data (tests/golden); read without the oracle package
+        fn = "pedigree_generated.txt" if name == "c2" else "pedigree.txt"
+        rows = [[float(t) for t in ln.replace("\t", " ").split()] for ln in
+                (ROOT / "tests" / "golden" / fn).read_text().splitlines()[1:] if ln.strip()]
+        ped = np.asarray(rows)
+        p = 0.6554051647850447 if name == "c2" else 0.75
+        lab = ("C2: bundled data/nodelist+edgelist pedigree (N=6 rows, T=4), 10 starts + 1000 bootstraps"
+               if name == "c2" else "G: reference golden pedigree data/pedigree.txt (N=351 rows, T=32, K=10), "
+                                    "10 starts + 1000 bootstraps")
+        return dict(gens=ped[:, :3], D=ped[:, 3][None, :], p0=np.array([p]), S=10, B=1000, wr=1, label=lab)
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(wl, model, pred, resid, lanes, seed, budget_s=12.0):
+    """The CPU oracle (a port of the reference's algorithm: per-row repeated 3x3 multiplication,
+    src/divergence.rs:51-90, one OpenMP thread per fit like the rayon par_iter) on a bounded sample."""
+    import oracle as O
+
+    O.build()
+    ped = np.concatenate([wl["gens"], wl["D"][0][:, None]], axis=1)
+    p0 = float(wl["p0"][0])
+    cores = O.max_threads()
+    nb = 64 * cores
+    t0 = time.perf_counter()
+    _, res = O.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, nb, lanes=1, table=False)
+    dt = time.perf_counter() - t0
+    scale = max(1.0, min(16.0, budget_s / max(dt, 1e-3)))
+    nb2 = int(nb * scale)
+    t0 = time.perf_counter()
+    _, res = O.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, nb2, lanes=1, table=False)
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    _, res_t = O.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, nb2, lanes=1, table=True)
+    dt_t = time.perf_counter() - t1
+    return {
+        "value": nb2 / dt, "unit": "fits/s", "cores": cores, "kind": "port",
+        "sample": f"{nb2} residual-bootstrap refits of window 0 (same pedigree, same inputs), reference-shaped "
+                  f"divergence (3 matrix_power per row), {cores} OpenMP threads, {dt:.1f} s",
+        "evals_per_s": float(res["evals"].sum()) / dt,
+        "power_table_variant_fits_per_s": nb2 / dt_t,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "g351"])
+    ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the ABneutral path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import alphabeta_rs_amd as A
+
+    A.load_library(build_if_missing=True)
+    seed = 20260101
+    wl = make_workload(args.workload, rank, world)
+    N, Wr, S, B = wl["gens"].shape[0], wl["wr"], wl["S"], wl["B"]
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = A.Context(local_rank, stream=stream)
+    opts = A.default_options(seed=seed, lanes_per_chain=args.lanes)
+    plan = A.Plan(ctx, wl["gens"], Wr, S, B, window_offset=rank * Wr, boot_offset=0, options=opts)
+    # the bootstrap table lives in a torch tensor so that RCCL can gather it without a copy
+    raw_local = torch.empty((Wr, B, 7), dtype=torch.float64, device="cuda")
+    plan.bind_raw(raw_local.data_ptr())
+    raw_all = torch.empty((world * Wr, B, 7), dtype=torch.float64, device="cuda") if world > 1 else raw_local
+    plan.set_windows(wl["D"], wl["p0"])          # H2D + index-buffer generation: outside the timed region
+
+    def step():
+        plan.run()                               # phase A -> select -> phase B on torch's current stream
+        if world > 1:
+            dist.all_gather_into_tensor(raw_all.view(-1), raw_local.view(-1))
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kms = {"fit_starts": 0.0, "select": 0.0, "fit_boot": 0.0}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    # per-kernel HIP-event durations (recorded on the launch stream): re-run K steps, reading the events
+    # after each one (reading forces a sync, so this loop is not the timed region)
+    for _ in range(args.steps):
+        plan.run()
+        ms = plan.kernel_ms()
+        for k in kms:
+            kms[k] += ms[k]
+    for k in kms:
+        kms[k] /= max(1, args.steps)
+    cnt = plan.counters()
+    out = plan.download()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([cnt["fits"], cnt["evals"], cnt["iters"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        tot_fits, tot_evals, tot_iters = (int(v) for v in c.tolist())
+    else:
+        tot_fits, tot_evals, tot_iters = cnt["fits"], cnt["evals"], cnt["iters"]
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        fits_per_s = tot_fits / (elapsed / args.steps)
+        evals_per_s = tot_evals / (elapsed / args.steps)
+        lanes = int(out["info_b"]["lanes"][0, 0])
+        K = len({tuple(r) for r in wl["gens"].astype(int).tolist()})
+        T = int(wl["gens"].max())
+        # ---- roofline of the dominant kernel (phase-B fit kernel), per launch on this rank
+        fits_b, evals_b = Wr * B, int(out["info_b"]["evals"].sum())
+        alg_bytes = fits_b * (4 * N + 56 + 32 + 24) + Wr * N * 16 + N * 2 + K * 4 + Wr * 56
+        kern_s = kms["fit_boot"] * 1e-3
+        achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
+        flops_eval = 45 * T + 53 * K + 4 * N + 60
+        valu_tflops = evals_b * flops_eval / kern_s / 1e12 if kern_s > 0 else 0.0
+        traffic = None
+        pmc = ROOT / "profiles" / "r01_pmc_fit_boot.json"
+        if pmc.exists():
+            try:
+                j = json.loads(pmc.read_text())
+                if j.get("workload") == args.workload:
+                    traffic = j.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": f"abn_fit_kernel<G={lanes}> phase B", "kernel_ms": kms["fit_boot"],
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "note": "register/LDS-resident fits: the index row is read once per fit, so the HBM roofline is "
+                    "nominal; the kernel is FP64-VALU/latency bound (see valu_fp64)",
+            "valu_fp64": {"achieved_tflops": valu_tflops, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
+                          "frac": valu_tflops / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": flops_eval},
+        }
+        result = {
+            "metric": "ABneutral model fits/sec (pedigree x bootstraps x windows)",
+            "value": fits_per_s, "unit": "fits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": wl["label"], "rows": N, "windows_per_gpu": Wr, "starts": S, "bootstraps": B,
+                       "lanes_per_chain": lanes, "parallelism": f"windows sharded over {world} GPU(s), one RCCL "
+                                                                 "all-gather of the bootstrap tables"},
+            "candidate_evals_per_s": evals_per_s,
+            "fits_per_step": tot_fits, "evals_per_step": tot_evals, "nm_iters_per_step": tot_iters,
+            "kernel_ms": kms,
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline:
+            bs = int(out["best_start"][0])
+            if bs >= 0:
+                result["cpu_baseline"] = cpu_baseline(wl, out["models"][0], out["pred"][0], out["resid"][0], lanes, seed)
+        print(json.dumps(result))
+    plan.close()
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

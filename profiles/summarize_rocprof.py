@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 CSVs of one bench.py run (kernel trace + separate --pmc passes) into the small
+summaries committed under profiles/.  Usage:
+  python profiles/summarize_rocprof.py gpurun_out/prof r01 c3
+Splits the two launches of abn_fit_kernel per step by grid size (phase A = starts, phase B = bootstraps).
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
+(MI355X_MICROARCH.md §HBM), so hbm_bytes_per_launch = 2*FETCH + WRITE is an upper-side estimate here
+(this kernel's loads are 4- and 8-byte per lane, an uncalibrated width)."""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+from pathlib import Path
+
+src, tag, workload = Path(sys.argv[1]), sys.argv[2], sys.argv[3]
+out = Path(__file__).resolve().parent
+
+stats = glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv"))[0]
+shutil.copy(stats, out / f"{tag}_kernel_stats.csv")
+
+trace = glob.glob(str(src / "kt" / "*" / "*_kernel_trace.csv"))[0]
+dur = collections.defaultdict(list)
+for r in csv.DictReader(open(trace)):
+    name = r["Kernel_Name"]
+    if "abn_fit_kernel" in name:
+        name += f" grid={r['Grid_Size_X']}"
+    dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+summary = {"workload": workload, "kernels": {}}
+for k, v in dur.items():
+    summary["kernels"][k] = {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
+
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
+    files = glob.glob(str(src / d / "*" / "*_counter_collection.csv"))
+    if not files:
+        continue
+    for r in csv.DictReader(open(files[0])):
+        name = r["Kernel_Name"]
+        if "abn_fit_kernel" in name:
+            name += f" grid={r['Grid_Size']}"
+        pmc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+summary["pmc_avg_per_launch"] = {k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in pmc.items()}
+big = [k for k in summary["pmc_avg_per_launch"] if "abn_fit_kernel" in k]
+if big:
+    b = max(big, key=lambda k: int(k.split("grid=")[1]))
+    p = summary["pmc_avg_per_launch"][b]
+    if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
+        hbm = (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
+        summary["phase_b_kernel"] = b
+        summary["hbm_bytes_per_launch"] = hbm
+        (out / f"{tag}_pmc_fit_boot.json").write_text(json.dumps(
+            {"workload": workload, "kernel": b, "FETCH_SIZE_KiB": p["FETCH_SIZE"], "WRITE_SIZE_KiB": p["WRITE_SIZE"],
+             "hbm_bytes_per_launch": hbm}, indent=1))
+(out / f"{tag}_rocprof_summary.json").write_text(json.dumps(summary, indent=1))
+print(json.dumps(summary, indent=1))
