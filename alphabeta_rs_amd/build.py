@@ -51,5 +51,34 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
     return LIB
 
 
+HOST = PKG / "host"
+CLI = PKG / "bin" / "alphabeta"
+PEDIGREE_LIB = PKG / "libabneutral_host.so"
+
+
+def build_host(force: bool = False, verbose: bool = False) -> Path:
+    """The C++ host layer: the `alphabeta` CLI (reference flags and output files) and a small shared
+    library exposing Pedigree::build to the tests.  Both link libabneutral_hip.so via $ORIGIN rpaths."""
+    build_hip()
+    srcs = [HOST / "alphabeta_cli.cpp", HOST / "alphabeta.hpp", HOST / "pedigree_build.hpp", HOST / "host_capi.cpp"]
+    newest = max(p.stat().st_mtime for p in srcs)
+    CLI.parent.mkdir(exist_ok=True)
+    common = ["-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-I", str(PKG.parent / "include")]
+    if force or not CLI.exists() or CLI.stat().st_mtime < newest:
+        cmd = [hipcc_path(), *common, "-o", str(CLI), str(HOST / "alphabeta_cli.cpp"), "-L", str(PKG),
+               "-labneutral_hip", "-Wl,-rpath,$ORIGIN/.."]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=str(PKG))
+    if force or not PEDIGREE_LIB.exists() or PEDIGREE_LIB.stat().st_mtime < newest:
+        cmd = [hipcc_path(), *common, "-fPIC", "-shared", "-o", str(PEDIGREE_LIB), str(HOST / "host_capi.cpp"), "-L",
+               str(PKG), "-labneutral_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=str(PKG))
+    return CLI
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
+    print(build_host(force=True, verbose=True))

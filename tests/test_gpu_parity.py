@@ -300,3 +300,34 @@ def test_full_size_properties_c3(abn, gpu_ctx, oracle):
     assert 0.5 < an[0, 0] / synthetic.TRUE_PARAMS[0] < 2.0
     assert 0.5 < an[0, 1] / synthetic.TRUE_PARAMS[1] < 2.0
     plan.close()
+
+
+# ------------------------------------------------------------------------------------------------ CLI
+def test_alphabeta_cli_end_to_end(abn, gpu_ctx, golden, oracle, tmp_path):
+    """The `alphabeta` binary (reference flags, src/arguments.rs:93-114) from raw nodelist/edgelist inputs:
+    pedigree.txt, analysis.txt and raw.npy (src/cli/alphabeta.rs:28-35) against the oracle pipeline."""
+    import subprocess
+    from pathlib import Path
+
+    from alphabeta_rs_amd import build as B
+
+    cli = str(B.build_host())
+    gold = Path(__file__).resolve().parent / "golden"
+    seed, iters = 5, 16
+    r = subprocess.run([cli, "-i", str(iters), "-n", "./data/nodelist.txt", "-e", "./data/edgelist.txt", "-o",
+                        str(tmp_path), "--seed", str(seed)], capture_output=True, text=True, cwd=str(gold))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Results:" in r.stdout and "Estimated steady state" in r.stdout
+    assert (tmp_path / "pedigree.txt").read_text() == (gold / "pedigree_generated.txt").read_text()
+    raw = np.load(tmp_path / "raw.npy")
+    assert raw.shape == (iters, 7)
+    ped, p0 = golden["generated"], golden["p0uu_generated"]
+    k, model, pred, resid, _, _ = _oracle_ab_neutral(oracle, abn, ped, p0, p0, 1.0, iters, seed, 8)
+    wraw, _ = oracle.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, iters, lanes=8)
+    assert np.array_equal(raw, wraw)
+    an = dict(ln.split("\t") for ln in (tmp_path / "analysis.txt").read_text().splitlines())
+    want = oracle.analyze(wraw)
+    assert float(an["Alpha"]) == want[0, 0] and float(an["SDBeta"]) == want[1, 1]
+    if want[2, 0] > 0 and want[3, 0] > 0:      # "lo-hi": unambiguous when both bounds are positive
+        lo, hi = an["CIAlpha"].split("-", 1)
+        assert float(lo) == want[2, 0] and float(hi) == want[3, 0]
