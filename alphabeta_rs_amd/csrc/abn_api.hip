@@ -112,7 +112,7 @@ static int build_topology(const double* rows, int n, int stride, Topology& t) {
   t.T = tmax;
   t.TP = tmax + 1;
   t.KP = (t.K + 1) & ~1;
-  t.chain_stride = 9 * t.TP + t.KP;
+  t.chain_stride = 9 * t.TP + t.KP + 4;  // power table, dt1t2 per triple, 4 per-chain constants
   return ABN_OK;
 }
 
@@ -134,6 +134,7 @@ static int upload_topology(abn_ctx* c, const Topology& t, DevTopology& d) {
 // launch configuration
 // ------------------------------------------------------------------------------------------------
 constexpr size_t kMaxDynLds = 64 * 1024;
+constexpr size_t kLdsResidentMax = 40 * 1024;  // above this the fit kernel streams rows instead of staging them
 
 // Lanes of a wavefront per chain.  Auto: by pedigree rows, then widened until the workgroup's LDS
 // (64/G chains x chain_stride doubles) leaves room for >= 8 workgroups per CU (160 KiB LDS).
@@ -144,7 +145,8 @@ static int pick_lanes(int n, int requested, int chain_stride) {
   if (n <= 32) g = 8;
   else if (n <= 128) g = 16;
   else if (n <= 256) g = 32;
-  while (g < 64 && (size_t)(kWave / g) * (size_t)chain_stride * sizeof(double) > kLdsTargetPerBlock) g *= 2;
+  const size_t per_chain = ((size_t)chain_stride + (size_t)n) * sizeof(double);  // scratch + resident observations
+  while (g < 64 && (size_t)(kWave / g) * per_chain > kLdsTargetPerBlock) g *= 2;
   return g;
 }
 static int pick_rmax(int n, int lanes) {
@@ -168,16 +170,22 @@ static hipError_t launch_fit_g(const FitArgs& a, int rmax, dim3 grid, size_t lds
   return hipGetLastError();
 }
 
-static int launch_fit(abn_ctx* c, const FitArgs& a, int lanes) {
+// `a.chain_stride` must be the topology's scratch stride (9*TP + KP + 4); the resident variant adds N doubles.
+static int launch_fit(abn_ctx* c, FitArgs a, int lanes) {
   const long long chains = (long long)a.W * a.C;
   if (chains <= 0) return ABN_OK;
   const int ng = kWave / lanes;
+  int rmax = pick_rmax(a.N, lanes);
+  const int np = (a.N + 1) & ~1;
+  if (rmax > 0) {
+    if ((size_t)ng * (size_t)(a.chain_stride + np) * sizeof(double) > kLdsResidentMax) rmax = 0;
+    else a.chain_stride += np;
+  }
   const size_t lds = (size_t)ng * (size_t)a.chain_stride * sizeof(double);
   if (lds > kMaxDynLds)
     return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS per workgroup than supported (T or K too large)");
   const long long blocks = (chains + ng - 1) / ng;
   if (blocks > 0x7fffffffLL) return set_err(c, ABN_ERR_INVALID_ARG, "too many chains for one launch");
-  const int rmax = pick_rmax(a.N, lanes);
   dim3 grid((unsigned)blocks);
   hipError_t e;
   switch (lanes) {
@@ -503,6 +511,7 @@ extern "C" int abn_fit_batch(abn_ctx* c, const abn_options* opts, const double* 
   a.max_iters = max_iters;
   a.shrink_variant = o.shrink_on_failed_contraction ? 1 : 0;
   a.sd_tol = o.sd_tolerance;
+  a.gap_tol = 64.0 * o.sd_tolerance;
   a.best = dbest.p;
   a.info = dinfo.p;
   a.raw = nullptr;
@@ -525,7 +534,8 @@ struct abn_plan {
   DevTopology dtopo;
   int N = 0, W = 0, S = 0, B = 0;
   uint32_t window_offset = 0, boot_offset = 0;
-  int lanes = 16;
+  int lanes = 16;    // phase B (throughput: many chains)
+  int lanes_a = 64;  // phase A (few chains: latency-bound, one wavefront per chain is fastest)
   bool windows_set = false, phase_a_done = false, ran_a = false, ran_b = false;
   DevBuf<double> D, pred, resid, p_uu, eqp, eqp_w, simplexA, bestA, model, lse, bestB, raw_own;
   DevBuf<FitInfoDev> infoA, infoB;
@@ -569,6 +579,8 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
     return set_err(c, rc, abn_status_string(rc));
   }
   p->lanes = pick_lanes(n_rows, p->opt.lanes_per_chain, p->topo.chain_stride);
+  p->lanes_a = p->lanes;
+  if (p->opt.lanes_per_chain == 0 && (long long)n_windows * n_starts <= 2048) p->lanes_a = 64;
   if ((size_t)(kWave / p->lanes) * p->topo.chain_stride * sizeof(double) > kMaxDynLds ||
       ((size_t)p->topo.chain_stride + kSelChunk) * sizeof(double) > kMaxDynLds) {
     delete p;
@@ -682,6 +694,7 @@ static void fill_common(const abn_plan* p, FitArgs& a) {
   a.W = p->W;
   a.shrink_variant = p->opt.shrink_on_failed_contraction ? 1 : 0;
   a.sd_tol = p->opt.sd_tolerance;
+  a.gap_tol = 64.0 * p->opt.sd_tolerance;
 }
 
 extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
@@ -702,7 +715,7 @@ extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
     a.info = p->infoA.p;
     a.raw = nullptr;
     HIPCHK(c, hipEventRecord(p->ev[0], c->stream));
-    int rc = launch_fit(c, a, p->lanes);
+    int rc = launch_fit(c, a, p->lanes_a);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(p->ev[1], c->stream));
     SelectArgs s{};
@@ -842,6 +855,32 @@ extern "C" int abn_plan_counters(abn_plan* p, int64_t* out3) {
   if (p->ran_b) rc = add(p->infoB);
   return rc;
 }
+
+#ifdef ABN_STAMPS
+// diagnostic build only: run phase A with in-kernel stamps, return the 8 cycle sums of chain 0
+extern "C" int abn_plan_debug_stamps(abn_plan* p, unsigned long long* out8) {
+  abn_ctx* c = p->ctx;
+  DevBuf<unsigned long long> d;
+  HIPCHK(c, d.alloc(8));
+  HIPCHK(c, hipMemsetAsync(d.p, 0, 64, c->stream));
+  FitArgs a{};
+  fill_common(p, a);
+  a.dmode = 0;
+  a.smode = 0;
+  a.simplex0 = p->simplexA.p;
+  a.C = p->S;
+  a.max_iters = p->opt.max_iters_start;
+  a.best = p->bestA.p;
+  a.info = p->infoA.p;
+  a.raw = nullptr;
+  a.dbg = d.p;
+  int rc = launch_fit(c, a, p->lanes);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(out8, d.p, 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ABN_OK;
+}
+#endif
 
 extern "C" int abn_plan_device_bytes(abn_plan* p, int64_t* bytes) {
   if (!p || !bytes) return ABN_ERR_INVALID_ARG;

@@ -69,11 +69,30 @@ struct FitArgs {
   int max_iters;
   int shrink_variant;
   double sd_tol;
+  double gap_tol;        // 64 * sd_tol, precomputed on the host so that it stays a scalar (kernarg) operand
   // outputs (fit order)
   double* best;          // [W*C*4]
   FitInfoDev* info;      // [W*C]
   double* raw;           // nullable [W*C*7] (src/boot_model.rs:86-91)
+  unsigned long long* dbg;  // diagnostic builds only (ABN_STAMPS): per-segment cycle sums of chain 0
 };
+
+// In-kernel stamps (MI355X guide §7): only in a separate diagnostic build, never in the shipped library.
+#ifdef ABN_STAMPS
+#define ABN_STAMP(slot)                                                           \
+  do {                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    unsigned long long t__;                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    seg[slot] += t__ - tprev;                                                     \
+    tprev = t__;                                                                  \
+  } while (0)
+#else
+#define ABN_STAMP(slot) \
+  do {                  \
+  } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // scalar pieces
@@ -127,40 +146,39 @@ __device__ __forceinline__ double group_sum(double v) {
 // on row r of G^(k-1): result.dot(matrix), src/divergence.rs:28).  Each product element is
 // fma(a_i2,b_2j, fma(a_i1,b_1j, fma(a_i0,b_0j, 0))) — matrixmultiply's k-ascending FMA accumulation.
 __device__ __forceinline__ void build_power_table(Gen Gm, int T, int TP, double* pw, int gl) {
+  (void)TP;
   // Opaque register copies: without them hipcc rewrites the lane-dependent row selects below into an
   // indexed load from a scratch copy of the matrix.
   asm("" : "+v"(Gm.g0), "+v"(Gm.g1), "+v"(Gm.g2));
   asm("" : "+v"(Gm.g3), "+v"(Gm.g4), "+v"(Gm.g5));
   asm("" : "+v"(Gm.g6), "+v"(Gm.g7), "+v"(Gm.g8));
-  const bool wr = gl < 3;
-  const bool is1 = (gl == 1), is2 = (gl == 2);  // every other lane mirrors row 0 and never stores
-  double r0 = (is1 || is2) ? 0.0 : 1.0, r1 = is1 ? 1.0 : 0.0, r2 = is2 ? 1.0 : 0.0;  // :21-24
-  double* prow = pw + 3 * (wr ? gl : 0);  // table layout pw[k][9]: entry k at k*9, row r at +3r
-  if (wr) {
+  if (gl < 3) {  // one exec mask for the whole chain of products: lanes 0..2 of each group, row gl
+    const bool is1 = (gl == 1), is2 = (gl == 2);
+    double r0 = (is1 || is2) ? 0.0 : 1.0, r1 = is1 ? 1.0 : 0.0, r2 = is2 ? 1.0 : 0.0;  // identity, :21-24
+    double* prow = pw + 3 * gl;  // table layout pw[k][9]: entry k at k*9, row r at +3r
     prow[0] = r0;
     prow[1] = r1;
     prow[2] = r2;
-  }
-  if (T >= 1) {
-    r0 = is2 ? Gm.g6 : (is1 ? Gm.g3 : Gm.g0);  // matrix.clone(), :25
-    r1 = is2 ? Gm.g7 : (is1 ? Gm.g4 : Gm.g1);
-    r2 = is2 ? Gm.g8 : (is1 ? Gm.g5 : Gm.g2);
-    if (wr) {
+    if (T >= 1) {
+      r0 = is2 ? Gm.g6 : (is1 ? Gm.g3 : Gm.g0);  // matrix.clone(), :25
+      r1 = is2 ? Gm.g7 : (is1 ? Gm.g4 : Gm.g1);
+      r2 = is2 ? Gm.g8 : (is1 ? Gm.g5 : Gm.g2);
       prow[9 + 0] = r0;
       prow[9 + 1] = r1;
       prow[9 + 2] = r2;
-    }
-    for (int k = 2; k <= T; ++k) {  // :27-29
-      const double n0 = fma3(r2, Gm.g6, fma3(r1, Gm.g3, fma3(r0, Gm.g0, 0.0)));
-      const double n1 = fma3(r2, Gm.g7, fma3(r1, Gm.g4, fma3(r0, Gm.g1, 0.0)));
-      const double n2 = fma3(r2, Gm.g8, fma3(r1, Gm.g5, fma3(r0, Gm.g2, 0.0)));
-      r0 = n0;
-      r1 = n1;
-      r2 = n2;
-      if (wr) {
-        prow[9 * k + 0] = r0;
-        prow[9 * k + 1] = r1;
-        prow[9 * k + 2] = r2;
+      double* pk = prow + 18;
+#pragma unroll 2
+      for (int k = 2; k <= T; ++k) {  // result = result.dot(matrix), :27-29
+        const double n0 = fma3(r2, Gm.g6, fma3(r1, Gm.g3, fma3(r0, Gm.g0, 0.0)));
+        const double n1 = fma3(r2, Gm.g7, fma3(r1, Gm.g4, fma3(r0, Gm.g1, 0.0)));
+        const double n2 = fma3(r2, Gm.g8, fma3(r1, Gm.g5, fma3(r0, Gm.g2, 0.0)));
+        r0 = n0;
+        r1 = n1;
+        r2 = n2;
+        pk[0] = r0;
+        pk[1] = r1;
+        pk[2] = r2;
+        pk += 9;
       }
     }
   }
@@ -171,21 +189,26 @@ __device__ __forceinline__ double cond_div(double a0, double a1, double a2, doub
   return 0.5 * (a0 * b1 + a1 * b0 + a1 * b2 + a2 * b1) + (a0 * b2 + a2 * b0);
 }
 
-// P3 for one distinct triple, src/divergence.rs:52-89
+// P3 for one distinct triple, src/divergence.rs:52-89.  Two load batches (G^t0, then G^a and G^b) with a
+// scheduling barrier in between keep the live registers of the fit kernel under 128 (4 wavefronts per SIMD).
 __device__ __forceinline__ double triple_dt(uint32_t tr, const double* pw, int TP, double sv0, double sv1,
                                             double sv2) {
+  (void)TP;
   const int t0 = tr & 0xff, ea = (tr >> 8) & 0xff, eb = (tr >> 16) & 0xff;
-  double P[9], A[9], B[9];
+  double P[9];
 #pragma unroll
-  for (int e = 0; e < 9; ++e) {  // pitch 9 doubles = 18 banks: 32 distinct exponents never conflict
-    P[e] = pw[t0 * 9 + e];
-    A[e] = pw[ea * 9 + e];
-    B[e] = pw[eb * 9 + e];
-  }
+  for (int e = 0; e < 9; ++e) P[e] = pw[t0 * 9 + e];  // pitch 9 doubles = 18 banks: 32 distinct exponents never conflict
   // svt0 = sv_gzero.t().dot(G^t0), :55
   const double s0 = fma3(sv2, P[6], fma3(sv1, P[3], fma3(sv0, P[0], 0.0)));
   const double s1 = fma3(sv2, P[7], fma3(sv1, P[4], fma3(sv0, P[1], 0.0)));
   const double s2 = fma3(sv2, P[8], fma3(sv1, P[5], fma3(sv0, P[2], 0.0)));
+  __builtin_amdgcn_sched_barrier(0);
+  double A[9], B[9];
+#pragma unroll
+  for (int e = 0; e < 9; ++e) {
+    A[e] = pw[ea * 9 + e];
+    B[e] = pw[eb * 9 + e];
+  }
   const double d_mm = cond_div(A[6], A[7], A[8], B[6], B[7], B[8]);  // :68-73
   const double d_um = cond_div(A[3], A[4], A[5], B[3], B[4], B[5]);  // :75-80
   const double d_uu = cond_div(A[0], A[1], A[2], B[0], B[1], B[2]);  // :82-87
@@ -232,21 +255,70 @@ __device__ __forceinline__ void sort5(double (&c)[5], double (&v)[5]) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The fit kernel.  RMAX > 0: "register mode" — each lane keeps its rows' observed divergences, row->
-// triple ids and its triples in registers for the whole fit (needs N <= G*RMAX); per evaluation the
-// only memory touched is the chain's LDS scratch.  RMAX == 0: "stream mode" for large pedigrees —
-// rows and triples are re-read every evaluation (bootstrap: the u32 index row is re-streamed).
+// Cross-lane helpers on DPP (no LDS crossbar): data-parallel-primitive moves have VALU latency, a
+// ds_bpermute round trip costs an LDS access.  All lanes of the wavefront are active at every call site.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int nlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, true);
+  const int nhi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(nhi, nlo);
+}
+constexpr int kDppQuadXor1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141; // lane i <-> 7-i  inside each 8 lanes
+constexpr int kDppRowMirror = 0x140;     // lane i <-> 15-i inside each 16 lanes
+constexpr int kDppQuadBcast0 = 0x00, kDppQuadBcast1 = 0x55, kDppQuadBcast2 = 0xAA, kDppQuadBcast3 = 0xFF;
+
+// v_permlane16_swap / v_permlane32_swap (gfx950) with both operands = v return (a, b) with
+// a + b = v[l] + v[l ^ 16] (resp. ^ 32) in every lane: the xor-16 / xor-32 butterfly step without LDS.
+template <int W>
+__device__ __forceinline__ double swap_sum(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  if (W == 16) {
+    const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  } else {
+    const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  }
+}
+
+// Sum over the G lanes of a group with the value tree of an xor-butterfly (offsets 1,2,4,...): after the
+// quad steps every quad is uniform, so the half-mirror / mirror partners hold exactly the values the xor-4 /
+// xor-8 partners would (addition is commutative), and the result is bit-identical to group_sum<G>.
+template <int G>
+__device__ __forceinline__ double group_sum_dpp(double v) {
+  v = v + dpp_mov<kDppQuadXor1>(v);
+  v = v + dpp_mov<kDppQuadXor2>(v);
+  if (G >= 8) v = v + dpp_mov<kDppRowHalfMirror>(v);
+  if (G >= 16) v = v + dpp_mov<kDppRowMirror>(v);
+  if (G >= 32) v = swap_sum<16>(v);
+  if (G >= 64) v = swap_sum<32>(v);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fit kernel.  RMAX > 0 ("resident", needs N <= G*RMAX): the chain's observed divergences
+// (bootstrap: pred_i + resid[idx_i], gathered once per fit) are staged in LDS, each lane keeps its
+// triples and its rows' triple ids in registers; an evaluation touches no global memory.
+// RMAX == 0 ("stream"): for larger pedigrees the rows are re-read every evaluation (bootstrap: the u32
+// index row is re-streamed from HBM, coalesced).
+// LDS per workgroup: 64/G chains x (9(T+1) + KP + 4 [+ NP]) doubles.
 // ------------------------------------------------------------------------------------------------
 template <int G, int RMAX>
-__global__ __launch_bounds__(kWave) void abn_fit_kernel(const FitArgs a) {
+__global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
   constexpr int NG = kWave / G;
+  constexpr bool STREAM = (RMAX == 0);
   constexpr int RR = RMAX > 0 ? RMAX : 1;
   extern __shared__ __align__(16) double lds[];
 
   const int lane = threadIdx.x;
   const int g = lane / G;
   const int gl = lane - g * G;
-  const int gbase = g * G;
   const int dim = gl & 3;
   const long long total = (long long)a.W * a.C;
   const long long chain_raw = (long long)blockIdx.x * NG + g;
@@ -258,33 +330,39 @@ __global__ __launch_bounds__(kWave) void abn_fit_kernel(const FitArgs a) {
 
   double* pw = lds + (size_t)g * a.chain_stride;
   double* dtab = pw + 9 * TP;
+  double* wconst = dtab + ((K + 1) & ~1);                                 // p0uu, p0mm, eqp, eqp_weight*N
+  double* dobs = wconst + 4;                                              // resident mode: N doubles
 
   const int wi = w * a.wstride;
-  const double p_uu0 = a.p_uu[wi];
-  const double p_mm = 1.0 - p_uu0;                    // src/ab_neutral.rs:23
-  const double eqp = a.eqp[wi];
-  const double ewN = a.eqp_w[wi] * (double)N;         // eqp_weight * nrows, src/structs.rs:210-211
   const size_t wN = (size_t)w * (size_t)N;
   const uint32_t* idx_row = a.dmode ? a.idx + (size_t)chain * (size_t)N : nullptr;
 
-  // ---- stage this lane's rows / triples (register mode)
-  double Dv[RR];
-  uint32_t tidv[RR], triv[RR];
-  if (RMAX > 0) {
+  // ---- per-chain constants live in LDS (they would otherwise pin 8 VGPRs for the whole fit)
+  if (gl == 0) {
+    const double p_uu0 = a.p_uu[wi];
+    wconst[0] = p_uu0;
+    wconst[1] = 1.0 - p_uu0;                          // p0mm, src/ab_neutral.rs:23
+    wconst[2] = a.eqp[wi];
+    wconst[3] = a.eqp_w[wi] * (double)N;              // eqp_weight * nrows, src/structs.rs:210-211
+  }
+  // ---- resident mode: observed divergences staged in LDS once per fit (bootstrap: gathered through the
+  // index row); this lane's triples and row->triple ids (as LDS byte offsets into dt) in registers
+  uint32_t triv[RR], tidp[(RR + 1) / 2];  // tidp: two 16-bit triple ids per register
+  if (!STREAM) {
+#pragma unroll
+    for (int q = 0; q < (RR + 1) / 2; ++q) tidp[q] = 0u;
 #pragma unroll
     for (int q = 0; q < RR; ++q) {
       const int i = gl + G * q;
-      Dv[q] = 0.0;
-      tidv[q] = 0;
-      triv[q] = 0;
+      triv[q] = (i < K) ? a.tri[i] : 0u;
       if (i < N) {
-        tidv[q] = a.tid[i];
-        Dv[q] = a.dmode ? a.pred[wN + i] + a.resid[wN + idx_row[i]]  // src/boot_model.rs:50-54
-                        : a.D[wN + i];
+        tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
+        dobs[i] = a.dmode ? a.pred[wN + i] + a.resid[wN + idx_row[i]]  // src/boot_model.rs:50-54
+                          : a.D[wN + i];
       }
-      if (i < K) triv[q] = a.tri[i];
     }
   }
+  __syncthreads();
 
   // ---- start simplex: this lane's dimension of the five vertices
   double vx[5], c[5];
@@ -306,34 +384,51 @@ __global__ __launch_bounds__(kWave) void abn_fit_kernel(const FitArgs a) {
     }
   }
 
-  // ---- one cost evaluation; xd = this lane's dimension of its group's candidate
+#ifdef ABN_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
+  // ---- one cost evaluation; xd = this lane's dimension of its group's candidate.  Lanes of a quad hold
+  // dimensions 0..3 of the same chain, so the candidate is re-assembled with four quad broadcasts.
   auto eval = [&](double xd) -> double {
-    const double al = __shfl(xd, gbase + 0, kWave), be = __shfl(xd, gbase + 1, kWave);
-    const double wt = __shfl(xd, gbase + 2, kWave), ic = __shfl(xd, gbase + 3, kWave);
+    ABN_STAMP(6);  // Nelder-Mead bookkeeping since the previous evaluation
+    const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
+    const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
     const Gen Gm = genmatrix(al, be);                        // P1
-    const double sv0 = p_uu0, sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;  // src/divergence.rs:44
+    const double p_mm = wconst[1];
+    const double sv0 = wconst[0], sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;  // src/divergence.rs:44
+    const double puu = p_uu_est(al, be);                     // src/divergence.rs:92 (early: overlaps P2)
+    const double dq = puu - wconst[2];
+    const double pen = wconst[3] * (dq * dq);                // src/structs.rs:210-212
+    ABN_STAMP(0);
     build_power_table(Gm, a.T, TP, pw, gl);                  // P2
     __syncthreads();
-    if (RMAX > 0) {                                          // P3
+    ABN_STAMP(1);
+    if (!STREAM) {                                           // P3
 #pragma unroll
       for (int q = 0; q < RR; ++q) {
         const int t = gl + G * q;
         if (t < K) dtab[t] = triple_dt(triv[q], pw, TP, sv0, sv1, sv2);
-        __builtin_amdgcn_sched_barrier(0);  // one triple's 27 table reads at a time (VGPR pressure)
+        __builtin_amdgcn_sched_barrier(0);  // one triple at a time (register pressure)
       }
     } else {
       for (int t = gl; t < K; t += G) dtab[t] = triple_dt(a.tri[t], pw, TP, sv0, sv1, sv2);
     }
     __syncthreads();
-    const double puu = p_uu_est(al, be);                     // src/divergence.rs:92
-    const double pen = ewN * ((puu - eqp) * (puu - eqp));    // src/structs.rs:210-212
+    ABN_STAMP(2);
     double acc = 0.0;                                        // P4
-    if (RMAX > 0) {
+    if (!STREAM) {
+      double dv[RR], tv[RR];
+#pragma unroll
+      for (int q = 0; q < RR; ++q) {                         // all LDS reads first, then the arithmetic
+        const bool in = (gl + G * q) < N;
+        dv[q] = in ? dobs[gl + G * q] : 0.0;
+        tv[q] = in ? dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu] : 0.0;
+      }
 #pragma unroll
       for (int q = 0; q < RR; ++q) {
-        const int i = gl + G * q;
-        if (i < N) {
-          const double r = Dv[q] - ic - dtab[tidv[q]];
+        if ((gl + G * q) < N) {
+          const double r = dv[q] - ic - tv[q];
           acc = acc + (r * r + pen);
         }
       }
@@ -344,122 +439,39 @@ __global__ __launch_bounds__(kWave) void abn_fit_kernel(const FitArgs a) {
         acc = acc + (r * r + pen);
       }
     }
-    acc = group_sum<G>(acc);                                 // P5
+    ABN_STAMP(3);
+    acc = group_sum_dpp<G>(acc);                             // P5
     __syncthreads();
+    ABN_STAMP(4);
     return acc;
   };
 
   // ---- evaluation-synchronous Nelder-Mead (argmin 0.8.1 NelderMead + Executor).
-  // One call site of the cost function; Solver::init and NelderMead::shrink evaluate "the vertex at a
-  // fixed position" and rotate the arrays, so no register array is ever indexed at run time.
-  int st = valid ? ST_INIT0 : ST_DONE;
+  // Solver::init and NelderMead::shrink evaluate "the vertex at a fixed position" and rotate the arrays,
+  // so no register array is ever indexed at run time; both live outside the hot loop.
+  int st = valid ? ST_REFLECT : ST_DONE;
   int iter = 0, evals = 0;
-  double xc = vx[0], x0 = 0.0, xr = 0.0, bx = __builtin_nan("");
+  double xc = 0.0, x0 = 0.0, xr = 0.0, bx = __builtin_nan("");
   double fr = 0.0, best_cost = __builtin_inf();
   bool have_best = false;
-#pragma unroll
-  for (int k = 0; k < 5; ++k) c[k] = 0.0;
+  int fin_status = 2;
 
-  while (__ballot(st != ST_DONE) != 0ull) {
-    const double f = eval(xc);
-    bool do_sort = false, do_insert = false, do_begin = false, start_shrink = false;
-    bool count_iter = true;
-    double xi = 0.0, fi = 0.0;
-    if (st != ST_DONE) {
-      ++evals;
-      if (st <= 4) {
-        // Solver::init: costs of the five start vertices in input order
-        c[0] = f;
-        const double tc = c[0], tv = vx[0];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          c[k] = c[k + 1];
-          vx[k] = vx[k + 1];
-        }
-        c[4] = tc;
-        vx[4] = tv;
-        if (st == 4) {
-          do_sort = true;
-          do_begin = true;
-          count_iter = false;
-        } else {
-          ++st;
-          xc = vx[0];
-        }
-      } else if (st == ST_REFLECT) {
-        fr = f;
-        if (fr < c[3] && fr >= c[0]) {        // reflection accepted
-          xi = xr;
-          fi = fr;
-          do_insert = true;
-        } else if (fr < c[0]) {               // try expansion: x0 + (xr - x0) * gamma
-          xc = x0 + (xr - x0) * 2.0;
-          st = ST_EXPAND;
-        } else if (fr >= c[3]) {              // contraction towards the worst: x0 + (xw - x0) * rho
-          xc = x0 + (vx[4] - x0) * 0.5;
-          st = ST_CONTRACT;
-        } else {                              // only reachable with a NaN cost
-          start_shrink = true;
-        }
-      } else if (st == ST_EXPAND) {
-        const bool take_e = f < fr;
-        xi = take_e ? xc : xr;
-        fi = take_e ? f : fr;
-        do_insert = true;
-      } else if (st == ST_CONTRACT) {
-        if (f < c[4]) {
-          xi = xc;
-          fi = f;
-          do_insert = true;
-        } else if (a.shrink_variant) {
-          start_shrink = true;
-        } else {
-          do_begin = true;  // argmin 0.8.1: a rejected contraction leaves the simplex as it is
-        }
-      } else {
-        // NelderMead::shrink, vertex k = st - 7 just evaluated at position 1; rotate positions 1..4
-        c[1] = f;
-        const double tc = c[1], tv = vx[1];
-#pragma unroll
-        for (int k = 1; k < 4; ++k) {
-          c[k] = c[k + 1];
-          vx[k] = vx[k + 1];
-        }
-        c[4] = tc;
-        vx[4] = tv;
-        if (st == ST_SHRINK1 + 3) {
-          do_sort = true;
-          do_begin = true;
-        } else {
-          ++st;
-          vx[1] = vx[0] + (vx[1] - vx[0]) * 0.5;
-          xc = vx[1];
-        }
-      }
-      if (start_shrink) {  // x0 + (p - x0) * sigma with x0 = best vertex, vertices 1..4 in order
-        vx[1] = vx[0] + (vx[1] - vx[0]) * 0.5;
-        xc = vx[1];
-        st = ST_SHRINK1;
-      }
-      if (do_sort) sort5(c, vx);
-      if (do_insert) {
-        c[4] = fi;
-        vx[4] = xi;
-        insert_tail<4>(c, vx);
-        do_begin = true;
-      }
+  // IterState::update() + terminate_internal() + the head of next_iter (centroid, reflection)
+  auto begin_iteration = [&](bool count_iter) {
+    const double c_best = c[0];
+    if (c_best < best_cost || (__builtin_isinf(c_best) && __builtin_isinf(best_cost) &&
+                               (__builtin_signbit(c_best) == __builtin_signbit(best_cost)))) {
+      bx = vx[0];
+      best_cost = c_best;
+      have_best = true;
     }
-    if (do_begin) {
-      // IterState::update(): keep the best-ever parameter vector
-      const double c_best = c[0];
-      if (c_best < best_cost || (__builtin_isinf(c_best) && __builtin_isinf(best_cost) &&
-                                 (__builtin_signbit(c_best) == __builtin_signbit(best_cost)))) {
-        bx = vx[0];
-        best_cost = c_best;
-        have_best = true;
-      }
-      if (count_iter) ++iter;
-      // terminate_internal: NelderMead::terminate (sample SD of the costs) -> max_iters -> target_cost
+    if (count_iter) ++iter;
+    // NelderMead::terminate (sample SD of the five costs < sd_tolerance) -> max_iters -> target_cost.
+    // Shortcut: with sorted finite costs some |c_k - mean| >= (c4 - c0)/2, so the computed SD is at least
+    // (c4 - c0)/4 (1 - 2^-50); a gap above 64*tol can never test as converged and the division and square
+    // root are skipped.  Any NaN makes the gap test false and falls through to the full form.
+    bool converged = false;
+    if (!((c[4] - c[0]) > a.gap_tol)) {
       double sum = 0.0;
 #pragma unroll
       for (int k = 0; k < 5; ++k) sum = sum + c[k];
@@ -468,41 +480,122 @@ __global__ __launch_bounds__(kWave) void abn_fit_kernel(const FitArgs a) {
 #pragma unroll
       for (int k = 0; k < 5; ++k) ss = ss + (c[k] - c0) * (c[k] - c0);
       const double sd = __builtin_sqrt(1.0 / (5.0 - 1.0) * ss);
-      int status = -1;
-      if (sd < a.sd_tol) status = 0;
-      else if (iter >= a.max_iters) status = 1;
-      else if (best_cost <= -__builtin_inf()) status = 3;
-      if (status >= 0) {
-        st = ST_DONE;
-        if (!have_best) status = 2;
-        if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
-        if (gl == 0) {
-          FitInfoDev fo;
-          fo.best_cost = best_cost;
-          fo.iters = iter;
-          fo.evals = evals;
-          fo.status = status;
-          fo.lanes = G;
-          a.info[chain] = fo;
+      converged = sd < a.sd_tol;
+    }
+    int status = -1;
+    if (converged) status = 0;
+    else if (iter >= a.max_iters) status = 1;
+    else if (best_cost <= -__builtin_inf()) status = 3;
+    // results are written after the loop (keeps output addresses out of the loop's registers); plain
+    // selects here: conditional stores to two different scalars made hipcc spill them to scratch
+    const bool done = status >= 0;
+    fin_status = done ? (have_best ? status : 2) : fin_status;
+    // centroid (p0 + p1 + p2 + p3) * (1/4), reflection x0 + (x0 - worst) * alpha
+    double acc = vx[0];
+    acc = acc + vx[1];
+    acc = acc + vx[2];
+    acc = acc + vx[3];
+    x0 = acc * (1.0 / 4.0);
+    xr = x0 + (x0 - vx[4]) * 1.0;
+    xc = xr;
+    st = done ? ST_DONE : ST_REFLECT;
+  };
+
+  // Solver::init: the five start costs in input order, stable sort, first termination check.  All chains
+  // of a wavefront start together.
+#pragma unroll 1
+  for (int k = 0; k < 5; ++k) {
+    const double f = eval(vx[0]);
+    const double tv = vx[0];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      c[q] = c[q + 1];
+      vx[q] = vx[q + 1];
+    }
+    c[4] = f;
+    vx[4] = tv;
+  }
+  if (valid) {
+    evals = 5;
+    sort5(c, vx);
+    begin_iteration(false);
+  }
+
+  while (__ballot(st != ST_DONE) != 0ull) {
+    const double f = eval(xc);
+    // ---- decisions of NelderMead::next_iter as predicates (no divergent control flow on the hot path)
+    const bool active = st != ST_DONE;
+    const bool is_ref = st == ST_REFLECT, is_exp = st == ST_EXPAND, is_con = st == ST_CONTRACT;
+    const bool acc_r = is_ref && (f < c[3]) && (f >= c[0]);      // reflection accepted
+    const bool go_exp = is_ref && !acc_r && (f < c[0]);           // try expansion
+    const bool go_con = is_ref && !acc_r && !go_exp && (f >= c[3]);  // contraction towards the worst
+    const bool nan_ref = is_ref && !acc_r && !go_exp && !go_con;  // only reachable with a NaN cost
+    const bool keep_r = is_exp && !(f < fr);                      // expansion not better: keep the reflection
+    const bool acc_c = is_con && (f < c[4]);
+    const bool rej_c = is_con && !acc_c;
+    const bool do_insert = acc_r || is_exp || acc_c;
+    const bool start_shrink = nan_ref || (rej_c && a.shrink_variant != 0);
+    const bool do_begin = do_insert || (rej_c && a.shrink_variant == 0);  // argmin 0.8.1: rejected contraction leaves the simplex
+    evals += active ? 1 : 0;
+    const double xi = keep_r ? xr : xc;
+    const double fi = keep_r ? fr : f;
+    fr = is_ref ? f : fr;
+    const double x_e = x0 + (xr - x0) * 2.0;        // expansion  x0 + (xr - x0) * gamma
+    const double x_c = x0 + (vx[4] - x0) * 0.5;     // contraction x0 + (xw - x0) * rho
+    xc = go_exp ? x_e : (go_con ? x_c : xc);
+    st = go_exp ? ST_EXPAND : (go_con ? ST_CONTRACT : st);
+    if (do_insert) {
+      c[4] = fi;
+      vx[4] = xi;
+      insert_tail<4>(c, vx);
+    }
+    if (do_begin) begin_iteration(true);
+    // ---- NelderMead::shrink (NaN costs, or the textbook variant after a rejected contraction): vertices
+    // 1..4 move towards the best by sigma and are re-evaluated in order.  Rare; the other chains idle.
+    if (__ballot(start_shrink) != 0ull) {
+#pragma unroll 1
+      for (int k = 1; k < 5; ++k) {
+        const double nv = vx[0] + (vx[1] - vx[0]) * 0.5;
+        const double fk = eval(start_shrink ? nv : xc);
+        if (start_shrink) {
+          ++evals;
+#pragma unroll
+          for (int q = 1; q < 4; ++q) {
+            c[q] = c[q + 1];
+            vx[q] = vx[q + 1];
+          }
+          c[4] = fk;
+          vx[4] = nv;
         }
-      } else {
-        // next_iter: centroid (p0 + p1 + p2 + p3) * (1/4), reflection x0 + (x0 - worst) * alpha
-        double acc = vx[0];
-        acc = acc + vx[1];
-        acc = acc + vx[2];
-        acc = acc + vx[3];
-        x0 = acc * (1.0 / 4.0);
-        xr = x0 + (x0 - vx[4]) * 1.0;
-        xc = xr;
-        st = ST_REFLECT;
+      }
+      if (start_shrink) {
+        sort5(c, vx);
+        begin_iteration(true);
       }
     }
   }
 
-  // ---- src/boot_model.rs:86-91: [alpha, beta, weight, intercept, est_mm, est_um, est_uu]
-  if (a.raw) {
-    const double b0 = __shfl(bx, gbase + 0, kWave), b1 = __shfl(bx, gbase + 1, kWave);
-    if (valid) {
+#ifdef ABN_STAMPS
+  if (a.dbg && chain_raw == 0 && gl == 0) {
+    for (int q = 0; q < 8; ++q) a.dbg[q] = seg[q];
+    a.dbg[7] = (unsigned long long)evals;
+  }
+#endif
+  // ---- results in fit order: best_param, (best_cost, iters, evals, status, lanes) and, for bootstraps,
+  // the row [alpha, beta, weight, intercept, est_mm, est_um, est_uu] of src/boot_model.rs:86-91
+  const double b0 = dpp_mov<kDppQuadBcast0>(bx), b1 = dpp_mov<kDppQuadBcast1>(bx);
+  if (valid) {
+    if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
+    if (gl == 0) {
+      FitInfoDev fo;
+      fo.best_cost = best_cost;
+      fo.iters = iter;
+      fo.evals = evals;
+      fo.status = fin_status;
+      fo.lanes = G;
+      a.info[chain] = fo;
+    }
+    if (a.raw) {
       double* ro = a.raw + (size_t)chain * 7;
       if (gl < 4) ro[gl] = bx;
       if (gl == 4) ro[4] = est_mm(b0, b1);

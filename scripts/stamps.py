@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Diagnostic build with in-kernel s_memtime stamps: where one evaluation of a lone chain spends its
+cycles.  Builds a separate libabneutral_hip_stamps.so (-DABN_STAMPS); never used by the product."""
+import ctypes as C, subprocess, sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+lib = ROOT / "gpurun_out" / "libabneutral_hip_stamps.so"
+lib.parent.mkdir(exist_ok=True)
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                "-DABN_STAMPS", "-o", str(lib), str(ROOT / "alphabeta_rs_amd/csrc/abn_api.hip")], check=True)
+import alphabeta_rs_amd as A
+A.LIB_PATH = lib
+A._lib = None
+L = A.load_library()
+L.abn_plan_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+from alphabeta_rs_amd import synthetic
+ctx = A.Context(0)
+ped, p0 = synthetic.c3_pedigree()
+names = ["P1 bcast+genmatrix+puu", "P2 power table", "P3 triples", "P4 rows", "P5 reduce", "-", "P6 NM update", "evals"]
+for lanes in (16, 64):
+    plan = A.Plan(ctx, ped[:, :3], 1, 1, 0, options=A.default_options(lanes_per_chain=lanes))
+    plan.set_windows(ped[:, 3][None, :], np.array([p0]))
+    out = (C.c_uint64 * 8)()
+    for _ in range(3):
+        rc = L.abn_plan_debug_stamps(plan._h, out)
+    assert rc == 0
+    ev = out[7]
+    print(f"lanes={lanes} evals={ev}")
+    tot = sum(out[q] for q in range(7))
+    for q in range(7):
+        if names[q] != "-":
+            print(f"  {names[q]:26s} {out[q] / ev:8.1f} cyc/eval  {100.0 * out[q] / tot:5.1f}%")
+    print(f"  total {tot / ev:.1f} cyc/eval (stamps add ~40 each)")
+    plan.close()

@@ -201,7 +201,8 @@ def test_ab_neutral_and_boot_model_match_oracle(abn, gpu_ctx, golden, oracle, ca
     assert np.array_equal(pred, wpred) and np.array_equal(resid, wresid)
     assert np.max(np.abs(pred - wpred)) <= 1e-6          # the stated tolerance, trivially met
     raw, info = gpu_ctx.boot_model_run(ped, model, pred, resid, p0, p0, 1.0, n_boot, options=o)
-    wraw, wres = oracle.boot_model(ped, wmodel, wpred, wresid, p0, p0, 1.0, seed, 0, 0, n_boot, lanes=lanes)
+    lanes_b = int(info["lanes"][0])   # phase B may use a different lane count than phase A
+    wraw, wres = oracle.boot_model(ped, wmodel, wpred, wresid, p0, p0, 1.0, seed, 0, 0, n_boot, lanes=lanes_b)
     assert np.array_equal(info["iters"], wres["iters"]) and np.array_equal(info["evals"], wres["evals"])
     assert np.array_equal(raw, wraw)
 
@@ -322,7 +323,8 @@ def test_alphabeta_cli_end_to_end(abn, gpu_ctx, golden, oracle, tmp_path):
     raw = np.load(tmp_path / "raw.npy")
     assert raw.shape == (iters, 7)
     ped, p0 = golden["generated"], golden["p0uu_generated"]
-    k, model, pred, resid, _, _ = _oracle_ab_neutral(oracle, abn, ped, p0, p0, 1.0, iters, seed, 8)
+    # auto lanes: phase A (16 chains) one wavefront per chain, phase B (6 rows) 8 lanes per chain
+    k, model, pred, resid, _, _ = _oracle_ab_neutral(oracle, abn, ped, p0, p0, 1.0, iters, seed, 64)
     wraw, _ = oracle.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, iters, lanes=8)
     assert np.array_equal(raw, wraw)
     an = dict(ln.split("\t") for ln in (tmp_path / "analysis.txt").read_text().splitlines())
