@@ -433,7 +433,31 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
         }
       }
     } else {
-      for (int i = gl; i < N; i += G) {
+      // stream mode: four rows per lane in flight (index row -> residual gather are dependent loads);
+      // the accumulation order per lane (rows gl, gl+G, ...) is unchanged
+      constexpr int U = 4;
+      int i = gl;
+      for (; i + (U - 1) * G < N; i += U * G) {
+        double d[U], t[U];
+        if (a.dmode) {
+          uint32_t ix[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) ix[u] = idx_row[i + u * G];
+#pragma unroll
+          for (int u = 0; u < U; ++u) d[u] = a.pred[wN + i + u * G] + a.resid[wN + ix[u]];
+        } else {
+#pragma unroll
+          for (int u = 0; u < U; ++u) d[u] = a.D[wN + i + u * G];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) t[u] = dtab[a.tid[i + u * G]];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const double r = d[u] - ic - t[u];
+          acc = acc + (r * r + pen);
+        }
+      }
+      for (; i < N; i += G) {
         const double d = a.dmode ? a.pred[wN + i] + a.resid[wN + idx_row[i]] : a.D[wN + i];
         const double r = d - ic - dtab[a.tid[i]];
         acc = acc + (r * r + pen);

@@ -11,7 +11,8 @@ is fixed) and there is no data-path collective other than the final gather.
 Workloads:  c3 (default) synthetic 100-edge / 8-generation pedigree, N=105 rows, 10 starts
 + 10000 bootstraps per window, one window per GPU;  c2 bundled pedigree (6 rows) x 1000 bootstraps;
 c4 the C3 topology, 25 windows x 1000 bootstraps per GPU (= 200 windows over 8 GPUs);  g351 the
-reference's golden pedigree (351 rows, T=32) x 1000 bootstraps.
+reference's golden pedigree (351 rows, T=32) x 1000 bootstraps;  c5s a single-GPU shard of C5 (20100 rows,
+T=125, 4096 bootstraps) in stream mode.
 """
 from __future__ import annotations
 
@@ -48,6 +49,14 @@ def make_workload(name: str, rank: int, world: int):
         return dict(gens=gens, D=D, p0=p0, S=10, B=1000, wr=25,
                     label="C4 shard: C3 topology, 25 windows x (10 starts + 1000 bootstraps) per GPU "
                           "(200 windows over 8 GPUs)")
+    if name == "c5s":
+        ped, p = synthetic.c5_pedigree()
+        rng = np.random.Generator(np.random.Philox(key=synthetic.SEED + 500 + rank))
+        D = np.maximum(ped[:, 3] + (rng.normal(0.0, synthetic.NOISE_SD, ped.shape[0]) if world > 1 else 0.0), 0.0)
+        return dict(gens=ped[:, :3], D=D[None, :], p0=np.array([p]), S=4, B=4096, wr=1,
+                    label="C5 shard: synthetic deep pedigree, 8 lineages x 125 generations (N=20100 rows, T=125, "
+                          "K=950), 4 starts + 4096 bootstraps, 1 window per GPU; rows streamed (u32 index row "
+                          "re-read from HBM every evaluation)")
     if name in ("c2", "g351"):
         # fixtures are data (tests/golden); read without the oracle package
         fn = "pedigree_generated.txt" if name == "c2" else "pedigree.txt"
@@ -97,7 +106,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "g351"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "g351", "c5s"])
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -182,13 +191,17 @@ def main():
         T = int(wl["gens"].max())
         # ---- roofline of the dominant kernel (phase-B fit kernel), per launch on this rank
         fits_b, evals_b = Wr * B, int(out["info_b"]["evals"].sum())
-        alg_bytes = fits_b * (4 * N + 56 + 32 + 24) + Wr * N * 16 + N * 2 + K * 4 + Wr * 56
+        stream = N > 8 * lanes            # stream mode: the index row is re-read every evaluation
+        if stream:
+            alg_bytes = evals_b * (4 * N + 40) + fits_b * 112 + Wr * N * 16 + N * 2 + K * 4 + Wr * 56
+        else:
+            alg_bytes = fits_b * (4 * N + 56 + 32 + 24) + Wr * N * 16 + N * 2 + K * 4 + Wr * 56
         kern_s = kms["fit_boot"] * 1e-3
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         flops_eval = 45 * T + 53 * K + 4 * N + 60
         valu_tflops = evals_b * flops_eval / kern_s / 1e12 if kern_s > 0 else 0.0
         traffic = None
-        pmc = ROOT / "profiles" / "r01_pmc_fit_boot.json"
+        pmc = ROOT / "profiles" / f"r01_pmc_fit_boot_{args.workload}.json"
         if pmc.exists():
             try:
                 j = json.loads(pmc.read_text())
@@ -201,8 +214,10 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "kernel": f"abn_fit_kernel<G={lanes}> phase B", "kernel_ms": kms["fit_boot"],
             "algorithmic_bytes_per_launch": alg_bytes,
-            "note": "register/LDS-resident fits: the index row is read once per fit, so the HBM roofline is "
-                    "nominal; the kernel is FP64-VALU/latency bound (see valu_fp64)",
+            "mode": "stream" if stream else "resident",
+            "note": ("stream mode: E*(4N+40) algorithmic bytes per fit (index row re-read per evaluation)" if stream
+                     else "LDS-resident fits: the index row is read once per fit, so the HBM roofline is nominal; "
+                          "the kernel is FP64-VALU/latency bound (see valu_fp64)"),
             "valu_fp64": {"achieved_tflops": valu_tflops, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                           "frac": valu_tflops / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": flops_eval},
         }

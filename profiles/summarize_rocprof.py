@@ -50,7 +50,7 @@ if big:
         hbm = (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
         summary["phase_b_kernel"] = b
         summary["hbm_bytes_per_launch"] = hbm
-        (out / f"{tag}_pmc_fit_boot.json").write_text(json.dumps(
+        (out / f"{tag}_pmc_fit_boot_{workload}.json").write_text(json.dumps(
             {"workload": workload, "kernel": b, "FETCH_SIZE_KiB": p["FETCH_SIZE"], "WRITE_SIZE_KiB": p["WRITE_SIZE"],
              "hbm_bytes_per_launch": hbm}, indent=1))
 (out / f"{tag}_rocprof_summary.json").write_text(json.dumps(summary, indent=1))

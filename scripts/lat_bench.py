@@ -37,6 +37,17 @@ def main():
     plan.run(); plan.run()
     out["c4"] = {k: round(v, 3) for k, v in plan.kernel_ms().items()}
     plan.close()
+    ped5, p5 = synthetic.c5_pedigree()
+    plan = A.Plan(ctx, ped5[:, :3], 1, 4, 256, options=A.default_options())
+    plan.set_windows(ped5[:, 3][None, :], np.array([p5]))
+    plan.run(); plan.run()
+    ms = plan.kernel_ms(); cnt = plan.counters()
+    d = plan.download()
+    evb = int(d["info_b"]["evals"].sum())
+    out["c5_256boots"] = dict(ms={k: round(v, 3) for k, v in ms.items()}, evals_b=evb,
+                              idx_stream_GBps=round(evb * 20100 * 4 / (ms["fit_boot"] * 1e-3) / 1e9, 1),
+                              max_evals_b=int(d["info_b"]["evals"].max()))
+    plan.close()
     print(json.dumps(out, indent=1))
 
 if __name__ == "__main__":
