@@ -37,13 +37,13 @@ def make_workload(name: str, rank: int, world: int):
     from alphabeta_rs_amd import synthetic
 
     if name == "c3":
-        gens, D, p0, _ = synthetic.c4_windows(1, window_offset=rank)
-        if world == 1:  # exactly BASELINE C3
-            ped, p = synthetic.c3_pedigree()
-            gens, D, p0 = ped[:, :3], ped[:, 3][None, :], np.array([p])
-        return dict(gens=gens, D=D, p0=p0, S=10, B=10000, wr=1,
+        # BASELINE C3 on every rank; for N > 1 GPUs the bootstraps of the one window are sharded: rank r owns
+        # bootstraps [r*10000, (r+1)*10000) (weak scaling: per-GPU work fixed), phase A (10 starts) is repeated
+        # on every rank (same inputs -> same bits) so that no exchange precedes phase B
+        ped, p = synthetic.c3_pedigree()
+        return dict(gens=ped[:, :3], D=ped[:, 3][None, :], p0=np.array([p]), S=10, B=10000, wr=1, shard="bootstraps",
                     label="C3: synthetic 100-edge/8-generation pedigree (N=105 rows, T=8, K=47 distinct triples), "
-                          "10 starts + 10000 bootstraps per window, 1 window per GPU")
+                          "10 starts + 10000 bootstraps per GPU (bootstraps of one window sharded over the GPUs)")
     if name == "c4":
         gens, D, p0, _ = synthetic.c4_windows(25, window_offset=25 * rank)
         return dict(gens=gens, D=D, p0=p0, S=10, B=1000, wr=25,
@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "g351", "c5s"])
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 ranks on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -121,10 +123,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the ABneutral path has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and args.backend == "nccl":
+        raise SystemExit(f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
+    local_rank = local_rank % ndev          # gloo rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import alphabeta_rs_amd as A
 
@@ -135,7 +141,9 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     ctx = A.Context(local_rank, stream=stream)
     opts = A.default_options(seed=seed, lanes_per_chain=args.lanes)
-    plan = A.Plan(ctx, wl["gens"], Wr, S, B, window_offset=rank * Wr, boot_offset=0, options=opts)
+    by_boot = wl.get("shard") == "bootstraps"
+    plan = A.Plan(ctx, wl["gens"], Wr, S, B, window_offset=0 if by_boot else rank * Wr,
+                  boot_offset=rank * B if by_boot else 0, options=opts)
     # the bootstrap table lives in a torch tensor so that RCCL can gather it without a copy
     raw_local = torch.empty((Wr, B, 7), dtype=torch.float64, device="cuda")
     plan.bind_raw(raw_local.data_ptr())
@@ -179,6 +187,11 @@ def main():
         c = torch.tensor([cnt["fits"], cnt["evals"], cnt["iters"]], dtype=torch.int64, device="cuda")
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         tot_fits, tot_evals, tot_iters = (int(v) for v in c.tolist())
+        if by_boot:  # the replicated phase-A fits are counted once
+            ia = out["info_a"]
+            tot_fits -= (world - 1) * ia.size
+            tot_evals -= (world - 1) * int(ia["evals"].sum())
+            tot_iters -= (world - 1) * int(ia["iters"].sum())
     else:
         tot_fits, tot_evals, tot_iters = cnt["fits"], cnt["evals"], cnt["iters"]
 
@@ -227,8 +240,8 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["label"], "rows": N, "windows_per_gpu": Wr, "starts": S, "bootstraps": B,
-                       "lanes_per_chain": lanes, "parallelism": f"windows sharded over {world} GPU(s), one RCCL "
-                                                                 "all-gather of the bootstrap tables"},
+                       "lanes_per_chain": lanes, "parallelism": f"{'bootstraps' if by_boot else 'windows'} sharded over {world} GPU(s), "
+                                                                 "one RCCL all-gather of the bootstrap tables"},
             "candidate_evals_per_s": evals_per_s,
             "fits_per_step": tot_fits, "evals_per_step": tot_evals, "nm_iters_per_step": tot_iters,
             "kernel_ms": kms,
