@@ -198,6 +198,32 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes) {
   return ABN_OK;
 }
 
+// Speculative three-wavefront kernel (phase A): resident mode with one wavefront per candidate only.
+static bool spec_applicable(const FitArgs& a) {
+  if (a.dmode != 0 || a.smode != 0) return false;
+  const int rmax = pick_rmax(a.N, kWave);
+  if (rmax == 0) return false;
+  const int np = (a.N + 1) & ~1;
+  return (3 * (size_t)(a.chain_stride + np) + 8) * sizeof(double) <= kLdsResidentMax;
+}
+
+static int launch_fit_spec(abn_ctx* c, FitArgs a) {
+  const long long chains = (long long)a.W * a.C;
+  if (chains <= 0) return ABN_OK;
+  const int rmax = pick_rmax(a.N, kWave);
+  a.chain_stride += (a.N + 1) & ~1;
+  const size_t lds = (3 * (size_t)a.chain_stride + 8) * sizeof(double);
+  dim3 grid((unsigned)chains), block(3 * kWave);
+  switch (rmax) {
+    case 1: hipLaunchKernelGGL(abn_fit_spec_kernel<1>, grid, block, lds, c->stream, a); break;
+    case 2: hipLaunchKernelGGL(abn_fit_spec_kernel<2>, grid, block, lds, c->stream, a); break;
+    case 4: hipLaunchKernelGGL(abn_fit_spec_kernel<4>, grid, block, lds, c->stream, a); break;
+    default: hipLaunchKernelGGL(abn_fit_spec_kernel<8>, grid, block, lds, c->stream, a); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  return ABN_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
@@ -715,7 +741,10 @@ extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
     a.info = p->infoA.p;
     a.raw = nullptr;
     HIPCHK(c, hipEventRecord(p->ev[0], c->stream));
-    int rc = launch_fit(c, a, p->lanes_a);
+    // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once
+    const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && (long long)p->W * p->S <= 2048 &&
+                      spec_applicable(a);
+    int rc = spec ? launch_fit_spec(c, a) : launch_fit(c, a, p->lanes_a);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(p->ev[1], c->stream));
     SelectArgs s{};

@@ -630,6 +630,271 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Speculative fit kernel for the latency-bound case (few chains, e.g. the S starts of phase A).
+// A Nelder-Mead iteration evaluates the reflection and then, depending on its cost, the expansion OR the
+// contraction point (argmin next_iter) — two dependent evaluations on ~70 % of the iterations.  All three
+// candidates are known before the first cost: x_r = x0 + (x0 - x_w), x_e = x0 + 2 (x_r - x0),
+// x_c = x0 + (x_w - x0)/2.  Here a chain owns a workgroup of THREE wavefronts (one per SIMD of a CU); each
+// evaluates one candidate with the G = 64 tree, the three costs are exchanged through LDS and every
+// wavefront takes the reference's decision on identical state.  Results, iteration and evaluation counts
+// (only evaluations the reference would have made are counted) are bit-identical to abn_fit_kernel<64,*>;
+// an iteration costs one evaluation latency instead of 1.7 on average.
+// Resident mode only (N <= 64*RMAX).  LDS: 3 x chain_stride doubles + 8 exchange doubles.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_fence() {  // orders this wavefront's LDS writes before its reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int RMAX>
+__global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a) {
+  constexpr int G = kWave;
+  extern __shared__ __align__(16) double lds[];
+  const int wv = threadIdx.x >> 6;      // 0: reflection, 1: expansion, 2: contraction
+  const int gl = threadIdx.x & 63;
+  const int dim = gl & 3;
+  const long long chain = blockIdx.x;   // grid = W*C exactly
+  const int w = (int)(chain / a.C);
+  const int N = a.N, K = a.K, TP = a.TP;
+
+  double* pw = lds + (size_t)wv * a.chain_stride;
+  double* dtab = pw + 9 * TP;
+  double* wconst = dtab + ((K + 1) & ~1);
+  double* dobs = wconst + 4;
+  double* xch = lds + (size_t)3 * a.chain_stride;  // two buffers of 3 costs (+ pad)
+
+  const int wi = w * a.wstride;
+  const size_t wN = (size_t)w * (size_t)N;
+  if (gl == 0) {
+    const double p_uu0 = a.p_uu[wi];
+    wconst[0] = p_uu0;
+    wconst[1] = 1.0 - p_uu0;
+    wconst[2] = a.eqp[wi];
+    wconst[3] = a.eqp_w[wi] * (double)N;
+  }
+  uint32_t triv[RMAX], tidp[(RMAX + 1) / 2];
+#pragma unroll
+  for (int q = 0; q < (RMAX + 1) / 2; ++q) tidp[q] = 0u;
+#pragma unroll
+  for (int q = 0; q < RMAX; ++q) {
+    const int i = gl + G * q;
+    triv[q] = (i < K) ? a.tri[i] : 0u;
+    if (i < N) {
+      tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
+      dobs[i] = a.D[wN + i];  // phase-A observations (dmode 0); bootstraps use abn_fit_kernel
+    }
+  }
+  __syncthreads();
+
+  double vx[5], c[5];
+  {
+    const double* s0 = a.simplex0 + (size_t)chain * 20;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) vx[k] = s0[4 * k + dim];
+  }
+
+  auto eval = [&](double xd) -> double {
+    const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
+    const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
+    const Gen Gm = genmatrix(al, be);
+    const double p_mm = wconst[1];
+    const double sv0 = wconst[0], sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;
+    const double puu = p_uu_est(al, be);
+    const double dq = puu - wconst[2];
+    const double pen = wconst[3] * (dq * dq);
+    build_power_table(Gm, a.T, TP, pw, gl);
+    wave_lds_fence();
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const int t = gl + G * q;
+      if (t < K) dtab[t] = triple_dt(triv[q], pw, TP, sv0, sv1, sv2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_lds_fence();
+    double acc = 0.0;
+    double dv[RMAX], tv[RMAX];
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const bool in = (gl + G * q) < N;
+      dv[q] = in ? dobs[gl + G * q] : 0.0;
+      tv[q] = in ? dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      if ((gl + G * q) < N) {
+        const double r = dv[q] - ic - tv[q];
+        acc = acc + (r * r + pen);
+      }
+    }
+    acc = group_sum_dpp<G>(acc);
+    wave_lds_fence();
+    return acc;
+  };
+
+  // exchange: every wavefront publishes its cost, one workgroup barrier, everybody reads all three
+  int phase = 0;
+  auto exchange = [&](double f, double& f0, double& f1, double& f2) {
+    double* buf = xch + 4 * phase;
+    if (gl == 0) buf[wv] = f;
+    __syncthreads();
+    f0 = buf[0];
+    f1 = buf[1];
+    f2 = buf[2];
+    phase ^= 1;  // the other buffer next time: no second barrier needed
+  };
+
+  int st = ST_REFLECT;
+  int iter = 0, evals = 0;
+  double x0 = 0.0, xr = 0.0, bx = __builtin_nan("");
+  double best_cost = __builtin_inf();
+  bool have_best = false;
+  int fin_status = 2;
+
+  auto begin_iteration = [&](bool count_iter) {
+    const double c_best = c[0];
+    if (c_best < best_cost || (__builtin_isinf(c_best) && __builtin_isinf(best_cost) &&
+                               (__builtin_signbit(c_best) == __builtin_signbit(best_cost)))) {
+      bx = vx[0];
+      best_cost = c_best;
+      have_best = true;
+    }
+    if (count_iter) ++iter;
+    bool converged = false;
+    if (!((c[4] - c[0]) > a.gap_tol)) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) sum = sum + c[k];
+      const double c0 = sum / 5.0;
+      double ss = 0.0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) ss = ss + (c[k] - c0) * (c[k] - c0);
+      const double sd = __builtin_sqrt(1.0 / (5.0 - 1.0) * ss);
+      converged = sd < a.sd_tol;
+    }
+    int status = -1;
+    if (converged) status = 0;
+    else if (iter >= a.max_iters) status = 1;
+    else if (best_cost <= -__builtin_inf()) status = 3;
+    const bool done = status >= 0;
+    fin_status = done ? (have_best ? status : 2) : fin_status;
+    double acc = vx[0];
+    acc = acc + vx[1];
+    acc = acc + vx[2];
+    acc = acc + vx[3];
+    x0 = acc * (1.0 / 4.0);
+    xr = x0 + (x0 - vx[4]) * 1.0;
+    st = done ? ST_DONE : ST_REFLECT;
+  };
+
+  // One call site of the cost function: `mode` (uniform over the workgroup) says what the three wavefronts
+  // evaluate this trip.  M_INIT1/2: Solver::init's five start costs (3 + 2); M_ITER: reflection, expansion,
+  // contraction; M_SHR1/2: NelderMead::shrink's four re-evaluations (3 + 1).
+  constexpr int M_INIT1 = 0, M_INIT2 = 1, M_ITER = 2, M_SHR1 = 3, M_SHR2 = 4, M_DONE = 5;
+  int mode = M_INIT1;
+  double x_e = 0.0, x_c = 0.0;
+  while (mode != M_DONE) {
+    double cand;
+    if (mode == M_INIT1) cand = wv == 0 ? vx[0] : (wv == 1 ? vx[1] : vx[2]);
+    else if (mode == M_INIT2) cand = wv == 0 ? vx[3] : vx[4];
+    else if (mode == M_ITER) {
+      x_e = x0 + (xr - x0) * 2.0;        // x0 + (xr - x0) * gamma
+      x_c = x0 + (vx[4] - x0) * 0.5;     // x0 + (xw - x0) * rho
+      cand = wv == 0 ? xr : (wv == 1 ? x_e : x_c);
+    } else if (mode == M_SHR1) cand = wv == 0 ? vx[1] : (wv == 1 ? vx[2] : vx[3]);
+    else cand = vx[4];
+    double f0, f1, f2;
+    exchange(eval(cand), f0, f1, f2);
+    bool start_shrink = false, sorted_begin = false;
+    if (mode == M_INIT1) {
+      c[0] = f0;
+      c[1] = f1;
+      c[2] = f2;
+      mode = M_INIT2;
+    } else if (mode == M_INIT2) {
+      c[3] = f0;
+      c[4] = f1;
+      evals = 5;
+      sort5(c, vx);
+      begin_iteration(false);
+      mode = (st == ST_DONE) ? M_DONE : M_ITER;
+    } else if (mode == M_ITER) {
+      const double fr = f0, fe = f1, fc = f2;
+      if (fr < c[3] && fr >= c[0]) {          // reflection accepted
+        evals += 1;
+        c[4] = fr;
+        vx[4] = xr;
+        insert_tail<4>(c, vx);
+        sorted_begin = true;
+      } else if (fr < c[0]) {                 // expansion
+        evals += 2;
+        const bool take_e = fe < fr;
+        c[4] = take_e ? fe : fr;
+        vx[4] = take_e ? x_e : xr;
+        insert_tail<4>(c, vx);
+        sorted_begin = true;
+      } else if (fr >= c[3]) {                // contraction
+        evals += 2;
+        if (fc < c[4]) {
+          c[4] = fc;
+          vx[4] = x_c;
+          insert_tail<4>(c, vx);
+          sorted_begin = true;
+        } else if (a.shrink_variant) {
+          start_shrink = true;
+        } else {
+          sorted_begin = true;                // argmin 0.8.1: rejected contraction leaves the simplex
+        }
+      } else {                                // NaN reflection cost
+        evals += 1;
+        start_shrink = true;
+      }
+      if (start_shrink) {
+#pragma unroll
+        for (int k = 1; k < 5; ++k) vx[k] = vx[0] + (vx[k] - vx[0]) * 0.5;
+        mode = M_SHR1;
+      }
+      if (sorted_begin) {
+        begin_iteration(true);
+        mode = (st == ST_DONE) ? M_DONE : M_ITER;
+      }
+    } else if (mode == M_SHR1) {
+      c[1] = f0;
+      c[2] = f1;
+      c[3] = f2;
+      mode = M_SHR2;
+    } else {  // M_SHR2
+      c[4] = f0;
+      evals += 4;
+      sort5(c, vx);
+      begin_iteration(true);
+      mode = (st == ST_DONE) ? M_DONE : M_ITER;
+    }
+  }
+
+  const double b0 = dpp_mov<kDppQuadBcast0>(bx), b1 = dpp_mov<kDppQuadBcast1>(bx);
+  if (wv == 0) {
+    if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
+    if (gl == 0) {
+      FitInfoDev fo;
+      fo.best_cost = best_cost;
+      fo.iters = iter;
+      fo.evals = evals;
+      fo.status = fin_status;
+      fo.lanes = G;
+      a.info[chain] = fo;
+    }
+    if (a.raw) {
+      double* ro = a.raw + (size_t)chain * 7;
+      if (gl < 4) ro[gl] = bx;
+      if (gl == 4) ro[4] = est_mm(b0, b1);
+      if (gl == 5) ro[5] = est_um(b0, b1);
+      if (gl == 6) ro[6] = p_uu_est(b0, b1);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Selection kernel: src/ab_neutral.rs:83-135.  One wavefront per window.  The pure LSE of each of the
 // S fitted models is summed SERIALLY in row order (the reference's `.sum::<f64>()`), the stable
 // arg-min taken (lowest start index on ties; NaN never wins), then predicted divergence and residuals
