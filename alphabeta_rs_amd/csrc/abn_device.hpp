@@ -142,20 +142,70 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
-// P2: lanes gl = 0,1,2 of a group own rows UU, UM, MM of the running power (row r of G^k depends only
-// on row r of G^(k-1): result.dot(matrix), src/divergence.rs:28).  Each product element is
-// fma(a_i2,b_2j, fma(a_i1,b_1j, fma(a_i0,b_0j, 0))) — matrixmultiply's k-ascending FMA accumulation.
+// ------------------------------------------------------------------------------------------------
+// Cross-lane helpers on DPP (no LDS crossbar): data-parallel-primitive moves have VALU latency, a
+// ds_bpermute round trip costs an LDS access.  All lanes of the wavefront are active at every call site.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int nlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, true);
+  const int nhi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(nhi, nlo);
+}
+constexpr int kDppQuadXor1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141; // lane i <-> 7-i  inside each 8 lanes
+constexpr int kDppRowMirror = 0x140;     // lane i <-> 15-i inside each 16 lanes
+constexpr int kDppQuadBcast0 = 0x00, kDppQuadBcast1 = 0x55, kDppQuadBcast2 = 0xAA, kDppQuadBcast3 = 0xFF;
+
+// P2: the power table G^0..G^T, left-accumulated exactly as the reference (result = result.dot(matrix),
+// src/divergence.rs:25-30): every product element is fma(a_i2,b_2j, fma(a_i1,b_1j, fma(a_i0,b_0j, 0))) —
+// matrixmultiply's k-ascending FMA accumulation.  Table layout pw[k][9] (entry k at k*9, row r at +3r).
+//
+// G = 16, 32 (several chains per wavefront, throughput-bound): nine lanes of the group, lane 4i+j holds
+// element (i,j) of the running power; the three operands R[i][0..2] are the other lanes of the same quad
+// (DPP quad broadcasts), so a step is 3 FMAs + 6 DPP moves + 1 LDS store instead of 9 FMAs + 3 stores
+// (-4 % time on C3's phase B).  G = 8 and G = 64: lanes 0..2 own one row each — with one chain per
+// wavefront the single dependent FMA chain of the nine-lane form is slower (measured: +25 % on the
+// latency-bound phase A of the 351-row pedigree), three independent row chains interleave better.
+template <int G>
 __device__ __forceinline__ void build_power_table(Gen Gm, int T, int TP, double* pw, int gl) {
   (void)TP;
-  // Opaque register copies: without them hipcc rewrites the lane-dependent row selects below into an
-  // indexed load from a scratch copy of the matrix.
+  // Opaque register copies: without them hipcc rewrites the lane-dependent selects below into an indexed
+  // load from a scratch copy of the matrix.
   asm("" : "+v"(Gm.g0), "+v"(Gm.g1), "+v"(Gm.g2));
   asm("" : "+v"(Gm.g3), "+v"(Gm.g4), "+v"(Gm.g5));
   asm("" : "+v"(Gm.g6), "+v"(Gm.g7), "+v"(Gm.g8));
-  if (gl < 3) {  // one exec mask for the whole chain of products: lanes 0..2 of each group, row gl
+  if (G == 16 || G == 32) {
+    if (gl < 12) {  // quads 0..2 of the group; lane position 3 of each quad mirrors position 2 and never stores
+      const int i = gl >> 2, jr = gl & 3;
+      const bool j1 = (jr == 1), j2 = (jr >= 2), st = (jr < 3);
+      const bool i1 = (i == 1), i2 = (i == 2);
+      const double gc0 = j2 ? Gm.g2 : (j1 ? Gm.g1 : Gm.g0);  // column j of G
+      const double gc1 = j2 ? Gm.g5 : (j1 ? Gm.g4 : Gm.g3);
+      const double gc2 = j2 ? Gm.g8 : (j1 ? Gm.g7 : Gm.g6);
+      const int j = j2 ? 2 : jr;
+      double* pe = pw + 3 * i + j;
+      double r = (i == j) ? 1.0 : 0.0;                        // identity, :21-24
+      if (st) pe[0] = r;
+      if (T >= 1) {
+        r = i2 ? gc2 : (i1 ? gc1 : gc0);                      // matrix.clone(), :25  (G[i][j])
+        if (st) pe[9] = r;
+        double* pk = pe + 18;
+        for (int k = 2; k <= T; ++k) {                        // :27-29
+          const double b0 = dpp_mov<kDppQuadBcast0>(r), b1 = dpp_mov<kDppQuadBcast1>(r);
+          const double b2 = dpp_mov<kDppQuadBcast2>(r);
+          r = fma3(b2, gc2, fma3(b1, gc1, fma3(b0, gc0, 0.0)));
+          if (st) pk[0] = r;
+          pk += 9;
+        }
+      }
+    }
+  } else if (gl < 3) {  // one exec mask for the whole chain of products: lanes 0..2 of each group, row gl
     const bool is1 = (gl == 1), is2 = (gl == 2);
     double r0 = (is1 || is2) ? 0.0 : 1.0, r1 = is1 ? 1.0 : 0.0, r2 = is2 ? 1.0 : 0.0;  // identity, :21-24
-    double* prow = pw + 3 * gl;  // table layout pw[k][9]: entry k at k*9, row r at +3r
+    double* prow = pw + 3 * gl;
     prow[0] = r0;
     prow[1] = r1;
     prow[2] = r2;
@@ -168,7 +218,7 @@ __device__ __forceinline__ void build_power_table(Gen Gm, int T, int TP, double*
       prow[9 + 2] = r2;
       double* pk = prow + 18;
 #pragma unroll 2
-      for (int k = 2; k <= T; ++k) {  // result = result.dot(matrix), :27-29
+      for (int k = 2; k <= T; ++k) {  // :27-29
         const double n0 = fma3(r2, Gm.g6, fma3(r1, Gm.g3, fma3(r0, Gm.g0, 0.0)));
         const double n1 = fma3(r2, Gm.g7, fma3(r1, Gm.g4, fma3(r0, Gm.g1, 0.0)));
         const double n2 = fma3(r2, Gm.g8, fma3(r1, Gm.g5, fma3(r0, Gm.g2, 0.0)));
@@ -255,22 +305,8 @@ __device__ __forceinline__ void sort5(double (&c)[5], double (&v)[5]) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cross-lane helpers on DPP (no LDS crossbar): data-parallel-primitive moves have VALU latency, a
-// ds_bpermute round trip costs an LDS access.  All lanes of the wavefront are active at every call site.
+// Cross-lane reductions
 // ------------------------------------------------------------------------------------------------
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int nlo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, true);
-  const int nhi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(nhi, nlo);
-}
-constexpr int kDppQuadXor1 = 0xB1;       // quad_perm:[1,0,3,2]
-constexpr int kDppQuadXor2 = 0x4E;       // quad_perm:[2,3,0,1]
-constexpr int kDppRowHalfMirror = 0x141; // lane i <-> 7-i  inside each 8 lanes
-constexpr int kDppRowMirror = 0x140;     // lane i <-> 15-i inside each 16 lanes
-constexpr int kDppQuadBcast0 = 0x00, kDppQuadBcast1 = 0x55, kDppQuadBcast2 = 0xAA, kDppQuadBcast3 = 0xFF;
-
 // v_permlane16_swap / v_permlane32_swap (gfx950) with both operands = v return (a, b) with
 // a + b = v[l] + v[l ^ 16] (resp. ^ 32) in every lane: the xor-16 / xor-32 butterfly step without LDS.
 template <int W>
@@ -401,7 +437,7 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
     const double dq = puu - wconst[2];
     const double pen = wconst[3] * (dq * dq);                // src/structs.rs:210-212
     ABN_STAMP(0);
-    build_power_table(Gm, a.T, TP, pw, gl);                  // P2
+    build_power_table<G>(Gm, a.T, TP, pw, gl);               // P2
     __syncthreads();
     ABN_STAMP(1);
     if (!STREAM) {                                           // P3
@@ -703,7 +739,7 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
     const double puu = p_uu_est(al, be);
     const double dq = puu - wconst[2];
     const double pen = wconst[3] * (dq * dq);
-    build_power_table(Gm, a.T, TP, pw, gl);
+    build_power_table<G>(Gm, a.T, TP, pw, gl);
     wave_lds_fence();
 #pragma unroll
     for (int q = 0; q < RMAX; ++q) {
@@ -932,7 +968,7 @@ __global__ __launch_bounds__(kWave) void abn_select_kernel(const SelectArgs a) {
   auto fill_dt = [&](const double* x) {
     const Gen Gm = genmatrix(x[0], x[1]);
     const double sv0 = p_uu0, sv1 = x[2] * p_mm, sv2 = (1.0 - x[2]) * p_mm;
-    build_power_table(Gm, a.T, TP, pw, lane);
+    build_power_table<kWave>(Gm, a.T, TP, pw, lane);
     __syncthreads();
     for (int t = lane; t < K; t += kWave) dtab[t] = triple_dt(a.tri[t], pw, TP, sv0, sv1, sv2);
     __syncthreads();
@@ -1032,7 +1068,7 @@ __global__ __launch_bounds__(kWave) void abn_cost_kernel(const CostArgs a) {
   }
   const Gen Gm = genmatrix(al, be);
   const double sv0 = a.p_uu0, sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;
-  build_power_table(Gm, a.T, TP, pw, gl);
+  build_power_table<G>(Gm, a.T, TP, pw, gl);
   __syncthreads();
   for (int t = gl; t < K; t += G) dtab[t] = triple_dt(a.tri[t], pw, TP, sv0, sv1, sv2);
   __syncthreads();
