@@ -54,7 +54,7 @@ class Options(C.Structure):
         ("shrink_on_failed_contraction", C.c_int32),
         ("max_iters_start", C.c_int32),
         ("max_iters_boot", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("stream_mode", C.c_int32),
         ("sd_tolerance", C.c_double),
     ]
 

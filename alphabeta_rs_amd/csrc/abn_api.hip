@@ -198,6 +198,13 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes) {
   return ABN_OK;
 }
 
+// true when launch_fit will use the stream variant for this pedigree / lane count
+static bool fit_streams(int n, int chain_stride, int lanes) {
+  if (pick_rmax(n, lanes) == 0) return true;
+  const int np = (n + 1) & ~1;
+  return (size_t)(kWave / lanes) * (size_t)(chain_stride + np) * sizeof(double) > kLdsResidentMax;
+}
+
 // Speculative three-wavefront kernel (phase A): resident mode with one wavefront per candidate only.
 static bool spec_applicable(const FitArgs& a) {
   if (a.dmode != 0 || a.smode != 0) return false;
@@ -235,7 +242,7 @@ extern "C" void abn_default_options(abn_options* o) {
   o->shrink_on_failed_contraction = 0;
   o->max_iters_start = 10000;  // src/ab_neutral.rs:62
   o->max_iters_boot = 1000;    // src/boot_model.rs:81
-  o->reserved0 = 0;
+  o->stream_mode = 0;
   o->sd_tolerance = 2.220446049250313e-16;  // f64::EPSILON
 }
 
@@ -567,6 +574,8 @@ struct abn_plan {
   DevBuf<FitInfoDev> infoA, infoB;
   DevBuf<int32_t> best_start;
   DevBuf<uint32_t> idx;
+  DevBuf<double> dstar;  // stream mode: materialised bootstrap observations [W x B x N]
+  bool stream_b = false;
   double* raw = nullptr;  // raw_own.p or caller-bound
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
@@ -641,6 +650,8 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   PALLOC(bestB, W * B * 4);
   PALLOC(infoB, W * B);
   PALLOC(raw_own, W * B * 7);
+  p->stream_b = n_boot > 0 && fit_streams(n_rows, p->topo.chain_stride, p->lanes) && p->opt.stream_mode == 0;
+  if (p->stream_b) PALLOC(dstar, W * B * N);
 #undef PALLOC
   p->raw = p->raw_own.p;
   for (auto& ev : p->ev)
@@ -787,6 +798,15 @@ extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
     a.info = p->infoB.p;
     a.raw = p->raw;
     HIPCHK(c, hipEventRecord(p->ev[4], c->stream));
+    if (p->stream_b) {  // gather the bootstrap observations once per fit, then stream them
+      const long long total = (long long)p->W * p->B * p->N;
+      const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 256LL * 64);
+      hipLaunchKernelGGL(abn_make_dstar_kernel, dim3(blocks), dim3(256), 0, c->stream, p->dstar.p, p->pred.p,
+                         p->resid.p, p->idx.p, p->N, (long long)p->B * p->N, total);
+      HIPCHK(c, hipGetLastError());
+      a.dmode = 2;
+      a.D = p->dstar.p;
+    }
     int rc = launch_fit(c, a, p->lanes);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(p->ev[5], c->stream));
@@ -917,6 +937,7 @@ extern "C" int abn_plan_device_bytes(abn_plan* p, int64_t* bytes) {
   t += p->D.bytes() + p->pred.bytes() + p->resid.bytes() + p->p_uu.bytes() + p->eqp.bytes() + p->eqp_w.bytes();
   t += p->simplexA.bytes() + p->bestA.bytes() + p->model.bytes() + p->lse.bytes() + p->bestB.bytes();
   t += p->raw_own.bytes() + p->infoA.bytes() + p->infoB.bytes() + p->best_start.bytes() + p->idx.bytes();
+  t += p->dstar.bytes();
   t += p->dtopo.tri.bytes() + p->dtopo.tid.bytes();
   *bytes = (int64_t)t;
   return ABN_OK;

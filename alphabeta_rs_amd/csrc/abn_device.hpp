@@ -24,6 +24,12 @@
 namespace abn {
 
 constexpr int kWave = 64;
+constexpr int kStreamVec = 4;  // consecutive rows per lane and block in stream mode
+
+// element-aligned vector types: global loads on gfx950 need dword alignment only
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4), aligned(2)));
+typedef double f64x2 __attribute__((ext_vector_type(2), aligned(8)));
 
 // ---- fit states of the evaluation-synchronous Nelder-Mead machine
 constexpr int ST_INIT0 = 0;     // 0..4: evaluating start vertex k           (argmin Solver::init)
@@ -53,7 +59,8 @@ struct FitArgs {
   const double* eqp_w;   // [W]
   int wstride;
   // observed divergences
-  int dmode;             // 0: D[w*N+i]   1: pred[w*N+i] + resid[w*N + idx[(w*C+j)*N+i]]
+  int dmode;             // 0: D[w*N+i]   1: pred[w*N+i] + resid[w*N + idx[(w*C+j)*N+i]]   2: D[chain*N+i]
+                         //    (2: bootstrap observations materialised once per fit by abn_make_dstar_kernel)
   const double* D;
   const double* pred;
   const double* resid;
@@ -371,7 +378,8 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
 
   const int wi = w * a.wstride;
   const size_t wN = (size_t)w * (size_t)N;
-  const uint32_t* idx_row = a.dmode ? a.idx + (size_t)chain * (size_t)N : nullptr;
+  const uint32_t* idx_row = (a.dmode == 1) ? a.idx + (size_t)chain * (size_t)N : nullptr;
+  const size_t dN = (a.dmode == 2) ? (size_t)chain * (size_t)N : wN;  // base of this chain's rows in a.D
 
   // ---- per-chain constants live in LDS (they would otherwise pin 8 VGPRs for the whole fit)
   if (gl == 0) {
@@ -393,8 +401,8 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
       triv[q] = (i < K) ? a.tri[i] : 0u;
       if (i < N) {
         tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
-        dobs[i] = a.dmode ? a.pred[wN + i] + a.resid[wN + idx_row[i]]  // src/boot_model.rs:50-54
-                          : a.D[wN + i];
+        dobs[i] = (a.dmode == 1) ? a.pred[wN + i] + a.resid[wN + idx_row[i]]  // src/boot_model.rs:50-54
+                                 : a.D[dN + i];
       }
     }
   }
@@ -469,34 +477,71 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
         }
       }
     } else {
-      // stream mode: four rows per lane in flight (index row -> residual gather are dependent loads);
-      // the accumulation order per lane (rows gl, gl+G, ...) is unchanged
-      constexpr int U = 4;
-      int i = gl;
-      for (; i + (U - 1) * G < N; i += U * G) {
-        double d[U], t[U];
-        if (a.dmode) {
-          uint32_t ix[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) ix[u] = idx_row[i + u * G];
-#pragma unroll
-          for (int u = 0; u < U; ++u) d[u] = a.pred[wN + i + u * G] + a.resid[wN + ix[u]];
+      // stream mode.  Lane l owns row blocks of kStreamVec = 4 consecutive rows: rows 4(l + G q) .. +3 for
+      // q = 0, 1, ... — so the u32 index row is read with one 16-byte load per lane (1 KiB per wavefront
+      // instruction), pred with two and the triple ids with one 8-byte load.  Two blocks (8 rows) per lane are
+      // in flight per iteration, the dependent residual gathers issued together.  The per-lane accumulation
+      // order (block by block, row by row) is what the oracle's lanes code `G | 3 << 8` reproduces.
+      constexpr int V = kStreamVec;
+      const int stride = V * G;
+      int base = V * gl;
+      for (; base + stride + V <= N; base += 2 * stride) {          // two full blocks
+        double d[2 * V], t[2 * V];
+        const u16x4 tq0 = *reinterpret_cast<const u16x4*>(a.tid + base);
+        const u16x4 tq1 = *reinterpret_cast<const u16x4*>(a.tid + base + stride);
+        if (a.dmode == 1) {
+          const u32x4 ix0 = *reinterpret_cast<const u32x4*>(idx_row + base);
+          const u32x4 ix1 = *reinterpret_cast<const u32x4*>(idx_row + base + stride);
+          const f64x2 p00 = *reinterpret_cast<const f64x2*>(a.pred + wN + base);
+          const f64x2 p01 = *reinterpret_cast<const f64x2*>(a.pred + wN + base + 2);
+          const f64x2 p10 = *reinterpret_cast<const f64x2*>(a.pred + wN + base + stride);
+          const f64x2 p11 = *reinterpret_cast<const f64x2*>(a.pred + wN + base + stride + 2);
+          const double* rs = a.resid + wN;
+          const double r0 = rs[ix0[0]], r1 = rs[ix0[1]], r2 = rs[ix0[2]], r3 = rs[ix0[3]];
+          const double r4 = rs[ix1[0]], r5 = rs[ix1[1]], r6 = rs[ix1[2]], r7 = rs[ix1[3]];
+          d[0] = p00[0] + r0;  // src/boot_model.rs:50-54
+          d[1] = p00[1] + r1;
+          d[2] = p01[0] + r2;
+          d[3] = p01[1] + r3;
+          d[4] = p10[0] + r4;
+          d[5] = p10[1] + r5;
+          d[6] = p11[0] + r6;
+          d[7] = p11[1] + r7;
         } else {
-#pragma unroll
-          for (int u = 0; u < U; ++u) d[u] = a.D[wN + i + u * G];
+          const f64x2 q00 = *reinterpret_cast<const f64x2*>(a.D + dN + base);
+          const f64x2 q01 = *reinterpret_cast<const f64x2*>(a.D + dN + base + 2);
+          const f64x2 q10 = *reinterpret_cast<const f64x2*>(a.D + dN + base + stride);
+          const f64x2 q11 = *reinterpret_cast<const f64x2*>(a.D + dN + base + stride + 2);
+          d[0] = q00[0];
+          d[1] = q00[1];
+          d[2] = q01[0];
+          d[3] = q01[1];
+          d[4] = q10[0];
+          d[5] = q10[1];
+          d[6] = q11[0];
+          d[7] = q11[1];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) t[u] = dtab[a.tid[i + u * G]];
+        for (int e = 0; e < V; ++e) {
+          t[e] = dtab[tq0[e]];
+          t[V + e] = dtab[tq1[e]];
+        }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const double r = d[u] - ic - t[u];
+        for (int e = 0; e < 2 * V; ++e) {
+          const double r = d[e] - ic - t[e];
           acc = acc + (r * r + pen);
         }
       }
-      for (; i < N; i += G) {
-        const double d = a.dmode ? a.pred[wN + i] + a.resid[wN + idx_row[i]] : a.D[wN + i];
-        const double r = d - ic - dtab[a.tid[i]];
-        acc = acc + (r * r + pen);
+      for (; base < N; base += stride) {                             // remaining (possibly partial) blocks
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+          const int i = base + e;
+          if (i < N) {
+            const double dd = (a.dmode == 1) ? a.pred[wN + i] + a.resid[wN + idx_row[i]] : a.D[dN + i];
+            const double r = dd - ic - dtab[a.tid[i]];
+            acc = acc + (r * r + pen);
+          }
+        }
       }
     }
     ABN_STAMP(3);
@@ -652,7 +697,7 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
       fo.iters = iter;
       fo.evals = evals;
       fo.status = fin_status;
-      fo.lanes = G;
+      fo.lanes = STREAM ? (G | ((kStreamVec - 1) << 8)) : G;  // reduction-tree code (oracle: `lanes`)
       a.info[chain] = fo;
     }
     if (a.raw) {
@@ -1106,6 +1151,24 @@ __global__ __launch_bounds__(kWave) void abn_cost_kernel(const CostArgs a) {
     }
     if (a.dt)
       for (int i = gl; i < N; i += G) a.dt[(size_t)m * N + i] = dtab[a.tid[i]];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Residual bootstrap observations, materialised once per fit for the stream mode (src/boot_model.rs:50-57):
+// dstar[(w*B + b)*N + i] = pred[w*N + i] + resid[w*N + idx[(w*B + b)*N + i]].  The index buffer is read
+// once, coalesced; the evaluations then stream dstar (8 B per row) instead of re-gathering through the index
+// row (4 B per row + an 8-byte random gather that, for tables beyond LDS, is bound by L2->L1 sector traffic).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void abn_make_dstar_kernel(double* dstar, const double* pred, const double* resid,
+                                                             const uint32_t* idx, int N, long long rows_per_window,
+                                                             long long total) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (long long)gridDim.x * blockDim.x) {
+    const long long w = t / rows_per_window;
+    const int i = (int)(t % N);
+    const size_t wN = (size_t)w * (size_t)N;
+    dstar[t] = pred[wN + i] + resid[wN + idx[t]];
   }
 }
 

@@ -122,11 +122,14 @@ def stream_probe(A, ctx, seed, steps=2):
     lanes = int(out["info_b"]["lanes"][0, 0])
     plan.close()
     alg = evals_b * (4 * N + 40) + B * 112 + N * 18
+    streamed = evals_b * (8 * N + 40) + B * (12 * N + 112)
     achieved = alg / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "kernel": f"abn_fit_kernel<G={lanes}, stream> phase B", "kernel_ms": ms,
-            "algorithmic_bytes_per_launch": alg,
-            "workload": f"C5 shard: N={N} rows, T=125, K=950, {B} bootstraps, {evals_b} evaluations x (4N+40) B"}
+            "traffic": None, "kernel": f"abn_fit_kernel<G={lanes & 0xff}, stream> phase B (+ abn_make_dstar_kernel)",
+            "kernel_ms": ms, "algorithmic_bytes_per_launch": alg, "streamed_bytes_per_launch": streamed,
+            "streamed_GBps": streamed / (ms * 1e-3) / 1e9, "streamed_frac": streamed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "workload": f"C5 shard: N={N} rows, T=125, K=950, {B} bootstraps, {evals_b} evaluations; `achieved` at "
+                        "SURVEY's 4N+40 B per evaluation, `streamed_*` at the 8N+40 B the kernel streams from HBM"}
 
 
 def main():
@@ -234,9 +237,14 @@ def main():
         T = int(wl["gens"].max())
         # ---- roofline of the dominant kernel (phase-B fit kernel), per launch on this rank
         fits_b, evals_b = Wr * B, int(out["info_b"]["evals"].sum())
-        stream = N > 8 * lanes            # stream mode: the index row is re-read every evaluation
+        stream = (lanes >> 8) != 0        # row-block code set: the pedigree is streamed every evaluation
+        lanes &= 0xff
         if stream:
+            # SURVEY.md §8(d) per-evaluation figure (4N + 40: the u32 index stream).  The default stream variant
+            # moves 8N + 40 per evaluation instead (materialised observations, no per-evaluation gather); its
+            # real stream rate is reported beside it as `streamed_*`.
             alg_bytes = evals_b * (4 * N + 40) + fits_b * 112 + Wr * N * 16 + N * 2 + K * 4 + Wr * 56
+            streamed_bytes = evals_b * (8 * N + 40) + fits_b * (12 * N + 112)  # tid (2 B/row) is L2-resident
         else:
             alg_bytes = fits_b * (4 * N + 56 + 32 + 24) + Wr * N * 16 + N * 2 + K * 4 + Wr * 56
         kern_s = kms["fit_boot"] * 1e-3
@@ -258,7 +266,11 @@ def main():
             "kernel": f"abn_fit_kernel<G={lanes}> phase B", "kernel_ms": kms["fit_boot"],
             "algorithmic_bytes_per_launch": alg_bytes,
             "mode": "stream" if stream else "resident",
-            "note": ("stream mode: E*(4N+40) algorithmic bytes per fit (index row re-read per evaluation)" if stream
+            **({"streamed_bytes_per_launch": streamed_bytes,
+                "streamed_GBps": streamed_bytes / kern_s / 1e9,
+                "streamed_frac": streamed_bytes / kern_s / 1e9 / HBM_PEAK_GBS} if stream else {}),
+            "note": ("stream mode: `achieved` prices an evaluation at SURVEY's 4N+40 B (index stream); the kernel "
+                     "streams the materialised observations, 8N+40 B per evaluation from HBM: streamed_*" if stream
                      else "LDS-resident fits: the index row is read once per fit, so the HBM roofline is nominal; "
                           "the kernel is FP64-VALU/latency bound (see valu_fp64)"),
             "valu_fp64": {"achieved_tflops": valu_tflops, "peak_tflops": FP64_VALU_PEAK_TFLOPS,

@@ -54,7 +54,9 @@ typedef struct abn_options {
   int32_t shrink_on_failed_contraction; /* 0 = argmin 0.8.1 behaviour; 1 = textbook Nelder-Mead        */
   int32_t max_iters_start;              /* 10000, src/ab_neutral.rs:62                                 */
   int32_t max_iters_boot;               /* 1000,  src/boot_model.rs:81                                 */
-  int32_t reserved0;
+  int32_t stream_mode;                  /* pedigrees too large for LDS: 0 = stream the bootstrap observations
+                                           (gathered once per fit, 8 B/row/evaluation); 1 = re-stream the u32
+                                           index row and gather residuals every evaluation (4 B/row + gather) */
   double sd_tolerance;                  /* f64::EPSILON (argmin default, never overridden)             */
 } abn_options;
 

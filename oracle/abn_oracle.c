@@ -203,14 +203,20 @@ double abo_cost(const double* ped, int n, const double* dobs, double p_uu, doubl
       }
       result = square_sum;
     } else {
+      /* lanes code: low byte = lanes of the butterfly; (code >> 8) + 1 = consecutive rows per lane and block
+       * (1: lane l takes rows l, l+lanes, ...; 4 (the stream kernel): rows 4(l + lanes q) .. +3) */
+      const int vec = (lanes >> 8) + 1;
+      lanes &= 0xff;
       double part[64];
       for (int l = 0; l < lanes; ++l) {
         double acc = 0.0;
-        for (int i = l; i < n; i += lanes) {
-          double d = dobs ? dobs[i] : ped[4 * i + 3];
-          double r = d - x[3] - dt[i];
-          acc += r * r + pen;
-        }
+        for (long base = (long)vec * l; base < n; base += (long)vec * lanes)
+          for (int e = 0; e < vec && base + e < n; ++e) {
+            const long i = base + e;
+            double d = dobs ? dobs[i] : ped[4 * i + 3];
+            double r = d - x[3] - dt[i];
+            acc += r * r + pen;
+          }
         part[l] = acc;
       }
       for (int off = 1; off < lanes; off <<= 1) {

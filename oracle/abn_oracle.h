@@ -76,6 +76,8 @@ int abo_divergence_table(const double* ped, int n, double p_mm, double p_uu, dou
 /* src/structs.rs:191-217.  dobs == NULL -> column 3 of ped.  lanes == 1 reproduces the reference's
  * serial row-order accumulation; lanes in {2,4,...,64} reproduces the HIP kernel's reduction: lane l
  * accumulates rows l, l+lanes, ... in increasing order, then an xor-butterfly (offsets 1,2,4,...).
+ * lanes may carry a row-block code in its upper bits: (lanes >> 8) + 1 consecutive rows per lane and block
+ * (the stream-mode kernel uses 4; abn_fit_info.lanes reports the same code, so tests pass it through).
  * table != 0 uses abo_divergence_table (same bits, faster). */
 double abo_cost(const double* ped, int n, const double* dobs, double p_uu, double eqp,
                 double eqp_weight, const double x[4], int lanes, int table);

@@ -131,8 +131,9 @@ def test_fit_batch_trajectories_bit_exact(abn, gpu_ctx, golden, oracle, lanes, v
         s0 = abn.gen_start_simplices(11 + lanes, 0, f, ped[:, 3].max())
         o = abn.default_options(lanes_per_chain=lanes, shrink_on_failed_contraction=variant)
         best, info = gpu_ctx.fit_batch(ped, p0, p0, 1.0, s0, iters, options=o)
-        want = oracle.fit_batch(ped, p0, p0, 1.0, s0, iters, shrink_variant=variant, lanes=lanes)
-        assert np.all(info["lanes"] == lanes)
+        code = int(info["lanes"][0])   # lanes, plus the row-block code when the pedigree is streamed
+        assert np.all(info["lanes"] == code) and (code & 0xff) == lanes
+        want = oracle.fit_batch(ped, p0, p0, 1.0, s0, iters, shrink_variant=variant, lanes=code)
         _assert_fits_equal(best, info, want)
 
 
@@ -147,7 +148,9 @@ def test_fit_batch_stream_mode_large_pedigree(abn, gpu_ctx, oracle):
     for lanes in (16, 64):
         o = abn.default_options(lanes_per_chain=lanes)
         best, info = gpu_ctx.fit_batch(ped, 0.75, 0.75, 1.0, s0, 300, options=o)
-        want = oracle.fit_batch(ped, 0.75, 0.75, 1.0, s0, 300, lanes=lanes)
+        code = int(info["lanes"][0])          # stream mode: lanes | (rows per block - 1) << 8
+        assert code & 0xff == lanes and code >> 8 == 3
+        want = oracle.fit_batch(ped, 0.75, 0.75, 1.0, s0, 300, lanes=code)
         _assert_fits_equal(best, info, want)
 
 
@@ -335,7 +338,8 @@ def test_alphabeta_cli_end_to_end(abn, gpu_ctx, golden, oracle, tmp_path):
         assert float(lo) == want[2, 0] and float(hi) == want[3, 0]
 
 
-def test_deep_pedigree_stream_mode_c5_shape(abn, gpu_ctx, oracle):
+@pytest.mark.parametrize("stream_mode", (0, 1))
+def test_deep_pedigree_stream_mode_c5_shape(abn, gpu_ctx, oracle, stream_mode):
     """BASELINE C5's pedigree (8 lineages x 125 generations, N = 20100 rows, T = 125, K = 950): the
     fit kernel streams the u32 bootstrap index row from HBM every evaluation.  A handful of starts and
     bootstraps, bit-equal to the oracle; the index-stream round trip is the property checked at size."""
@@ -345,7 +349,9 @@ def test_deep_pedigree_stream_mode_c5_shape(abn, gpu_ctx, oracle):
     n = ped.shape[0]
     assert n == 20100 and ped[:, :3].max() == 125
     seed = 31
-    o = abn.default_options(seed=seed, max_iters_start=60, max_iters_boot=40)
+    # stream_mode 0: bootstrap observations materialised once per fit and streamed (8 B/row/evaluation);
+    # stream_mode 1: the u32 index row re-streamed and residuals gathered every evaluation.  Same bits.
+    o = abn.default_options(seed=seed, max_iters_start=60, max_iters_boot=40, stream_mode=stream_mode)
     plan = abn.Plan(gpu_ctx, ped[:, :3], 1, 3, 6, options=o)
     plan.set_windows(ped[:, 3][None, :], np.array([p0]))
     plan.run()
