@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "abn_default_options", "abn_device_count", "abn_init", "abn_shutdown", "abn_last_error",
     "abn_status_string", "abn_version", "abn_cost_batch", "abn_fit_batch", "abn_gen_start_simplices",
     "abn_gen_boot_simplices", "abn_gen_boot_indices", "abn_ab_neutral_run", "abn_boot_model_run",
-    "abn_analyze", "abn_plan_create", "abn_plan_destroy", "abn_plan_set_windows", "abn_plan_run",
+    "abn_analyze", "abn_select_best", "abn_bootstrap_rows", "abn_plan_create", "abn_plan_destroy", "abn_plan_set_windows", "abn_plan_run",
     "abn_plan_run_phase", "abn_plan_sync", "abn_plan_kernel_ms", "abn_plan_raw_device_ptr",
     "abn_plan_bind_raw", "abn_plan_download", "abn_plan_counters", "abn_plan_device_bytes",
 ]
@@ -105,6 +105,8 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     L.abn_boot_model_run.argtypes = [vp, op, dp, C.c_int32, dp, dp, dp, C.c_double, C.c_double, C.c_double,
                                      C.c_int32, dp, vp]
     L.abn_analyze.argtypes = [dp, C.c_int64, dp]
+    L.abn_select_best.argtypes = [vp, dp, C.c_int32, C.c_double, dp, C.c_int32, C.POINTER(C.c_int32), dp, dp, dp, dp]
+    L.abn_bootstrap_rows.argtypes = [vp, dp, C.c_int64, dp]
     L.abn_plan_create.argtypes = [vp, op, dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,
                                   C.POINTER(vp)]
     L.abn_plan_destroy.argtypes = [vp]
@@ -268,6 +270,24 @@ class Context:
                                                eqp_weight, n_starts, _dp(model), _dp(pred), _dp(resid), _dp(allm),
                                                info.ctypes.data, _dp(lse)))
         return model, pred, resid, {"models": allm, "info": info, "lse": lse}
+
+    def select_best(self, pedigree, p0uu, models):
+        """src/ab_neutral.rs:83-135: (index, model, pred, resid, lse)"""
+        ped = _f64(pedigree).reshape(-1, 4)
+        m = _f64(models).reshape(-1, 4)
+        n = ped.shape[0]
+        k = C.c_int32(-1)
+        model, pred, resid, lse = np.empty(4), np.empty(n), np.empty(n), np.empty(m.shape[0])
+        self._check(self._L.abn_select_best(self._h, _dp(ped), n, p0uu, _dp(m), m.shape[0], C.byref(k), _dp(model),
+                                            _dp(pred), _dp(resid), _dp(lse)))
+        return k.value, model, pred, resid, lse
+
+    def bootstrap_rows(self, best):
+        """src/boot_model.rs:86-91"""
+        b = _f64(best).reshape(-1, 4)
+        raw = np.empty((b.shape[0], 7))
+        self._check(self._L.abn_bootstrap_rows(self._h, _dp(b), b.shape[0], _dp(raw)))
+        return raw
 
     # ---- (3) boot_model::run
     def boot_model_run(self, pedigree, model, pred, resid, p0uu, eqp, eqp_weight, n_boot, *,

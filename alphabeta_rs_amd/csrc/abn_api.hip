@@ -1004,6 +1004,90 @@ extern "C" int abn_boot_model_run(abn_ctx* c, const abn_options* opts, const dou
 }
 
 // ------------------------------------------------------------------------------------------------
+// stand-alone selection and bootstrap rows
+// ------------------------------------------------------------------------------------------------
+extern "C" int abn_select_best(abn_ctx* c, const double* pedigree, int32_t n_rows, double p0uu, const double* models,
+                               int32_t n_models, int32_t* best_index, double* model, double* pred, double* resid,
+                               double* lse) {
+  if (!c) return ABN_ERR_INVALID_ARG;
+  if (!pedigree || n_rows <= 0 || !models || n_models <= 0 || !best_index)
+    return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
+  HIPCHK(c, hipSetDevice(c->device));
+  Topology t;
+  int rc = build_topology(pedigree, n_rows, 4, t);
+  if (rc) return set_err(c, rc, abn_status_string(rc));
+  const size_t lds = ((size_t)9 * t.TP + t.KP + kSelChunk) * sizeof(double);
+  if (lds > kMaxDynLds) return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS than supported");
+  DevTopology dt;
+  rc = upload_topology(c, t, dt);
+  if (rc) return rc;
+  const size_t N = (size_t)n_rows, S = (size_t)n_models;
+  std::vector<double> dcol(N);
+  for (size_t i = 0; i < N; ++i) dcol[i] = pedigree[i * 4 + 3];
+  DevBuf<double> dD, dm, dlse, dmodel, dpred, dresid, dp;
+  DevBuf<FitInfoDev> dinfo;
+  DevBuf<int32_t> dbest;
+  HIPCHK(c, dD.alloc(N));
+  HIPCHK(c, dm.alloc(S * 4));
+  HIPCHK(c, dlse.alloc(S));
+  HIPCHK(c, dmodel.alloc(4));
+  HIPCHK(c, dpred.alloc(N));
+  HIPCHK(c, dresid.alloc(N));
+  HIPCHK(c, dp.alloc(1));
+  HIPCHK(c, dinfo.alloc(S));
+  HIPCHK(c, dbest.alloc(1));
+  HIPCHK(c, hipMemcpyAsync(dD.p, dcol.data(), dD.bytes(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dm.p, models, dm.bytes(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(dp.p, &p0uu, sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dinfo.p, 0, dinfo.bytes(), c->stream));  // status 0: every model is a candidate
+  SelectArgs a{};
+  a.tri = dt.tri.p;
+  a.tid = dt.tid.p;
+  a.N = n_rows;
+  a.K = t.K;
+  a.T = t.T;
+  a.TP = t.TP;
+  a.p_uu = dp.p;
+  a.D = dD.p;
+  a.models = dm.p;
+  a.info = dinfo.p;
+  a.W = 1;
+  a.S = n_models;
+  a.lse = dlse.p;
+  a.model = dmodel.p;
+  a.pred = dpred.p;
+  a.resid = dresid.p;
+  a.best_start = dbest.p;
+  hipLaunchKernelGGL(abn_select_kernel, dim3(1), dim3(kWave), lds, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(best_index, dbest.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  if (model) HIPCHK(c, hipMemcpyAsync(model, dmodel.p, dmodel.bytes(), hipMemcpyDeviceToHost, c->stream));
+  if (pred) HIPCHK(c, hipMemcpyAsync(pred, dpred.p, dpred.bytes(), hipMemcpyDeviceToHost, c->stream));
+  if (resid) HIPCHK(c, hipMemcpyAsync(resid, dresid.p, dresid.bytes(), hipMemcpyDeviceToHost, c->stream));
+  if (lse) HIPCHK(c, hipMemcpyAsync(lse, dlse.p, dlse.bytes(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (*best_index < 0) return set_err(c, ABN_ERR_NO_FINITE_FIT, abn_status_string(ABN_ERR_NO_FINITE_FIT));
+  return ABN_OK;
+}
+
+extern "C" int abn_bootstrap_rows(abn_ctx* c, const double* best, int64_t n_boot, double* raw) {
+  if (!c) return ABN_ERR_INVALID_ARG;
+  if (!best || !raw || n_boot < 0) return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
+  if (n_boot == 0) return ABN_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf<double> db, dr;
+  HIPCHK(c, db.alloc((size_t)n_boot * 4));
+  HIPCHK(c, dr.alloc((size_t)n_boot * 7));
+  HIPCHK(c, hipMemcpyAsync(db.p, best, db.bytes(), hipMemcpyHostToDevice, c->stream));
+  const unsigned blocks = (unsigned)std::min<long long>((n_boot + 255) / 256, 4096);
+  hipLaunchKernelGGL(abn_rows_kernel, dim3(blocks), dim3(256), 0, c->stream, db.p, (long long)n_boot, dr.p);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(raw, dr.p, dr.bytes(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return ABN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // src/analysis.rs:50-98 on the host (ndarray mean / Welford std with mul_add, ndarray-stats Linear CI)
 // ------------------------------------------------------------------------------------------------
 extern "C" int abn_analyze(const double* raw, int64_t n_boot, double* out32) {

@@ -1154,6 +1154,21 @@ __global__ __launch_bounds__(kWave) void abn_cost_kernel(const CostArgs a) {
   }
 }
 
+// src/boot_model.rs:86-91 for a batch of fitted vectors (abn_bootstrap_rows)
+__global__ __launch_bounds__(256) void abn_rows_kernel(const double* best, long long n, double* raw) {
+  for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+    const double al = best[4 * t + 0], be = best[4 * t + 1];
+    double* ro = raw + 7 * t;
+    ro[0] = al;
+    ro[1] = be;
+    ro[2] = best[4 * t + 2];
+    ro[3] = best[4 * t + 3];
+    ro[4] = est_mm(al, be);
+    ro[5] = est_um(al, be);
+    ro[6] = p_uu_est(al, be);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Residual bootstrap observations, materialised once per fit for the stream mode (src/boot_model.rs:50-57):
 // dstar[(w*B + b)*N + i] = pred[w*N + i] + resid[w*N + idx[(w*B + b)*N + i]].  The index buffer is read

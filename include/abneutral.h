@@ -120,6 +120,17 @@ int abn_ab_neutral_run(abn_ctx* ctx, const abn_options* opts, const double* pedi
                        double* pred, double* resid, double* all_models, abn_fit_info* info,
                        double* lse);
 
+/* src/ab_neutral.rs:83-135 on its own: stable arg-min by pure LSE (serial row order, no penalty term) over
+ * S fitted models, then predicted divergence and residuals of the winner.  NaN never wins; *best_index = -1
+ * (and ABN_ERR_NO_FINITE_FIT) if every LSE is NaN.  lse[S] optional. */
+int abn_select_best(abn_ctx* ctx, const double* pedigree, int32_t n_rows, double p0uu, const double* models,
+                    int32_t n_models, int32_t* best_index, double* model, double* pred, double* resid,
+                    double* lse);
+
+/* src/boot_model.rs:86-91 on its own: raw[B x 7] = [alpha, beta, weight, intercept, est_mm, est_um, est_uu]
+ * (src/structs.rs:146-159) from fitted vectors best[B x 4], evaluated on the device. */
+int abn_bootstrap_rows(abn_ctx* ctx, const double* best, int64_t n_boot, double* raw);
+
 /* ------------------------------------------------------------------ (3) boot_model::run
  * src/boot_model.rs:17-115 without the PNG (:105-109): n_boot residual-bootstrap refits.
  * raw[n_boot x 7] = [alpha,beta,weight,intercept,PrMM,PrUM,PrUU] rows (RawAnalysis, src/analysis.rs:12),

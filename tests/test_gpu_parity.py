@@ -265,6 +265,25 @@ def test_device_sqrt_and_division_are_correctly_rounded(abn, gpu_ctx, oracle):
         assert np.array_equal(row, oracle.bootstrap_row(row[:4]))
 
 
+def test_select_best_and_bootstrap_rows_standalone(abn, gpu_ctx, golden, oracle):
+    """src/ab_neutral.rs:83-135 and src/boot_model.rs:86-91 as stand-alone entry points."""
+    ped, p0 = golden["sparse"], golden["r_p0uu"]
+    rng = np.random.default_rng(12)
+    models = np.array([5.8e-05, 6.5e-03, 0.03, 6e-05]) * rng.uniform(0.5, 1.5, (9, 4))
+    models[3] = models[7]                       # an exact tie: the lower index must win (stable sort)
+    models[5, 0] = np.nan                       # NaN LSE never wins
+    k, model, pred, resid, lse = gpu_ctx.select_best(ped, p0, models)
+    wk, wmodel, wpred, wresid, wlse = oracle.select_best(ped, p0, models)
+    assert k == wk and np.array_equal(model, wmodel)
+    assert np.array_equal(pred, wpred) and np.array_equal(resid, wresid)
+    assert np.array_equal(lse[~np.isnan(wlse)], wlse[~np.isnan(wlse)]) and np.isnan(lse[5])
+    with pytest.raises(abn.AbnError) as e:
+        gpu_ctx.select_best(ped, p0, np.full((2, 4), np.nan))
+    assert e.value.status == 5
+    raw = gpu_ctx.bootstrap_rows(models[:5])
+    assert np.array_equal(raw, np.stack([oracle.bootstrap_row(m) for m in models[:5]]))
+
+
 # ------------------------------------------------------------------------------------------------ properties
 def test_full_size_properties_c3(abn, gpu_ctx, oracle):
     """BASELINE config C3 (105 rows, 10000 bootstraps) at full size through size-independent properties:
