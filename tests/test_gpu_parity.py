@@ -387,3 +387,64 @@ def test_deep_pedigree_stream_mode_c5_shape(abn, gpu_ctx, oracle, stream_mode):
     assert np.array_equal(out["raw"][0], wraw)
     assert np.array_equal(out["info_b"]["evals"][0], wres["evals"])
     plan.close()
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+def test_edge_cases_tiny_and_degenerate_pedigrees(abn, gpu_ctx, oracle):
+    """Smallest inputs and degenerate generations: one row, one start, one bootstrap; all generations 0
+    (T = 0: only G^0 = I is ever used); generation 127 (the i8 ceiling); all-zero divergences
+    (Model::new falls back to max = 0.1, src/structs.rs:80-83)."""
+    cases = {
+        "one_row": np.array([[0.0, 1.0, 2.0, 0.01]]),
+        "all_gen_zero": np.array([[0.0, 0.0, 0.0, 0.02], [0.0, 0.0, 0.0, 0.03], [0.0, 0.0, 0.0, 0.01]]),
+        "gen_127": np.array([[0.0, 127.0, 3.0, 0.2], [5.0, 127.0, 127.0, 0.3], [0.0, 1.0, 1.0, 0.01]]),
+        "zero_divergence": np.array([[0.0, 1.0, 2.0, 0.0], [0.0, 2.0, 2.0, 0.0], [1.0, 2.0, 3.0, 0.0]]),
+    }
+    for name, ped in cases.items():
+        for n_starts, n_boot in ((1, 1), (3, 5)):
+            o = abn.default_options(seed=9, max_iters_start=400, max_iters_boot=200)
+            plan = abn.Plan(gpu_ctx, ped[:, :3], 1, n_starts, n_boot, options=o)
+            plan.set_windows(ped[:, 3][None, :], np.array([0.8]))
+            plan.run()
+            out = plan.download()
+            plan.close()
+            la, lb = int(out["info_a"]["lanes"][0, 0]), int(out["info_b"]["lanes"][0, 0])
+            s0 = abn.gen_start_simplices(9, 0, n_starts, ped[:, 3].max())
+            fits = oracle.fit_batch(ped, 0.8, 0.8, 1.0, s0, 400, lanes=la)
+            assert np.array_equal(out["info_a"]["evals"][0], fits["evals"]), name
+            assert np.array_equal(out["info_a"]["status"][0], fits["status"]), name
+            k, model, pred, resid, _ = oracle.select_best(ped, 0.8, fits["best"])
+            assert out["best_start"][0] == k, name
+            if k >= 0:
+                assert np.array_equal(out["models"][0], model), name
+                wraw, wres = oracle.boot_model(ped, model, pred, resid, 0.8, 0.8, 1.0, 9, 0, 0, n_boot, max_iters=200,
+                                               lanes=lb)
+                assert np.array_equal(out["raw"][0], wraw, equal_nan=True), name
+                assert np.array_equal(out["info_b"]["evals"][0], wres["evals"]), name
+
+
+def test_invalid_arguments_are_status_codes(abn, gpu_ctx, golden):
+    import ctypes as C
+
+    L = abn.load_library()
+    ped = golden["generated"]
+    dp = ped.ctypes.data_as(C.POINTER(C.c_double))
+    out = np.zeros(8)
+    op = out.ctypes.data_as(C.POINTER(C.c_double))
+    # null pointers / non-positive sizes -> ABN_ERR_INVALID_ARG (1), never a crash
+    assert L.abn_cost_batch(gpu_ctx._h, None, None, 6, 0.7, 0.7, 1.0, dp, 1, None, None, None, None, 0, op, None, None) == 1
+    assert L.abn_cost_batch(gpu_ctx._h, None, dp, 0, 0.7, 0.7, 1.0, dp, 1, None, None, None, None, 0, op, None, None) == 1
+    assert L.abn_fit_batch(gpu_ctx._h, None, dp, 6, 0.7, 0.7, 1.0, None, 1, None, 10, op, None) == 1
+    assert L.abn_ab_neutral_run(gpu_ctx._h, None, dp, 6, 0.7, 0.7, 1.0, 0, op, op, op, None, None, None) == 1
+    assert L.abn_boot_model_run(gpu_ctx._h, None, dp, 6, op, op, op, 0.7, 0.7, 1.0, 0, op, None) == 1
+    h = C.c_void_p()
+    assert L.abn_plan_create(gpu_ctx._h, None, dp, 6, 0, 1, 1, 0, 0, C.byref(h)) == 1
+    assert L.abn_init(99, None, C.byref(h)) == 1
+    # plan used out of order -> ABN_ERR_STATE (6)
+    plan = abn.Plan(gpu_ctx, ped[:, :3], 1, 2, 2)
+    with pytest.raises(abn.AbnError) as e:
+        plan.run()
+    assert e.value.status == 6
+    plan.close()
+    # zero candidates / fits are fine
+    assert gpu_ctx.cost_batch(ped, 0.7, 0.7, 1.0, np.zeros((0, 4))).shape == (0,)
