@@ -56,6 +56,8 @@ class Options(C.Structure):
         ("max_iters_boot", C.c_int32),
         ("stream_mode", C.c_int32),
         ("sd_tolerance", C.c_double),
+        ("window_groups", C.c_int32),
+        ("reserved1", C.c_int32),
     ]
 
 

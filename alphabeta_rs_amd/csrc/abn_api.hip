@@ -24,6 +24,7 @@ struct abn_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   bool own_stream = false;
+  std::vector<hipStream_t> side;  // lazily created: window groups of a plan run concurrently on these
   std::string err;
 };
 
@@ -171,7 +172,7 @@ static hipError_t launch_fit_g(const FitArgs& a, int rmax, dim3 grid, size_t lds
 }
 
 // `a.chain_stride` must be the topology's scratch stride (9*TP + KP + 4); the resident variant adds N doubles.
-static int launch_fit(abn_ctx* c, FitArgs a, int lanes) {
+static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
   const long long chains = (long long)a.W * a.C;
   if (chains <= 0) return ABN_OK;
   const int ng = kWave / lanes;
@@ -189,10 +190,10 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes) {
   dim3 grid((unsigned)blocks);
   hipError_t e;
   switch (lanes) {
-    case 8: e = launch_fit_g<8>(a, rmax, grid, lds, c->stream); break;
-    case 16: e = launch_fit_g<16>(a, rmax, grid, lds, c->stream); break;
-    case 32: e = launch_fit_g<32>(a, rmax, grid, lds, c->stream); break;
-    default: e = launch_fit_g<64>(a, rmax, grid, lds, c->stream); break;
+    case 8: e = launch_fit_g<8>(a, rmax, grid, lds, st); break;
+    case 16: e = launch_fit_g<16>(a, rmax, grid, lds, st); break;
+    case 32: e = launch_fit_g<32>(a, rmax, grid, lds, st); break;
+    default: e = launch_fit_g<64>(a, rmax, grid, lds, st); break;
   }
   HIPCHK(c, e);
   return ABN_OK;
@@ -214,7 +215,7 @@ static bool spec_applicable(const FitArgs& a) {
   return (3 * (size_t)(a.chain_stride + np) + 8) * sizeof(double) <= kLdsResidentMax;
 }
 
-static int launch_fit_spec(abn_ctx* c, FitArgs a) {
+static int launch_fit_spec(abn_ctx* c, FitArgs a, hipStream_t st) {
   const long long chains = (long long)a.W * a.C;
   if (chains <= 0) return ABN_OK;
   const int rmax = pick_rmax(a.N, kWave);
@@ -222,10 +223,10 @@ static int launch_fit_spec(abn_ctx* c, FitArgs a) {
   const size_t lds = (3 * (size_t)a.chain_stride + 8) * sizeof(double);
   dim3 grid((unsigned)chains), block(3 * kWave);
   switch (rmax) {
-    case 1: hipLaunchKernelGGL(abn_fit_spec_kernel<1>, grid, block, lds, c->stream, a); break;
-    case 2: hipLaunchKernelGGL(abn_fit_spec_kernel<2>, grid, block, lds, c->stream, a); break;
-    case 4: hipLaunchKernelGGL(abn_fit_spec_kernel<4>, grid, block, lds, c->stream, a); break;
-    default: hipLaunchKernelGGL(abn_fit_spec_kernel<8>, grid, block, lds, c->stream, a); break;
+    case 1: hipLaunchKernelGGL(abn_fit_spec_kernel<1>, grid, block, lds, st, a); break;
+    case 2: hipLaunchKernelGGL(abn_fit_spec_kernel<2>, grid, block, lds, st, a); break;
+    case 4: hipLaunchKernelGGL(abn_fit_spec_kernel<4>, grid, block, lds, st, a); break;
+    default: hipLaunchKernelGGL(abn_fit_spec_kernel<8>, grid, block, lds, st, a); break;
   }
   HIPCHK(c, hipGetLastError());
   return ABN_OK;
@@ -244,6 +245,8 @@ extern "C" void abn_default_options(abn_options* o) {
   o->max_iters_boot = 1000;    // src/boot_model.rs:81
   o->stream_mode = 0;
   o->sd_tolerance = 2.220446049250313e-16;  // f64::EPSILON
+  o->window_groups = 0;
+  o->reserved1 = 0;
 }
 
 static abn_options resolve(const abn_options* o) {
@@ -293,6 +296,7 @@ extern "C" int abn_init(int device_ordinal, void* stream, abn_ctx** out) {
 extern "C" int abn_shutdown(abn_ctx* c) {
   if (!c) return ABN_ERR_INVALID_ARG;
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+  for (auto st : c->side) (void)hipStreamDestroy(st);
   delete c;
   return ABN_OK;
 }
@@ -549,7 +553,7 @@ extern "C" int abn_fit_batch(abn_ctx* c, const abn_options* opts, const double* 
   a.info = dinfo.p;
   a.raw = nullptr;
   const int lanes = pick_lanes(N, o.lanes_per_chain, t.chain_stride);
-  rc = launch_fit(c, a, lanes);
+  rc = launch_fit(c, a, lanes, c->stream);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(best, dbest.p, dbest.bytes(), hipMemcpyDeviceToHost, c->stream));
   if (info) HIPCHK(c, hipMemcpyAsync(info, dinfo.p, dinfo.bytes(), hipMemcpyDeviceToHost, c->stream));
@@ -578,12 +582,16 @@ struct abn_plan {
   bool stream_b = false;
   double* raw = nullptr;  // raw_own.p or caller-bound
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr;
+  std::vector<hipEvent_t> ev_join;
 };
 
 extern "C" int abn_plan_destroy(abn_plan* p) {
   if (!p) return ABN_ERR_INVALID_ARG;
   for (auto& e : p->ev)
     if (e) (void)hipEventDestroy(e);
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  for (auto e : p->ev_join) (void)hipEventDestroy(e);
   delete p;
   return ABN_OK;
 }
@@ -734,6 +742,99 @@ static void fill_common(const abn_plan* p, FitArgs& a) {
   a.gap_tol = 64.0 * p->opt.sd_tolerance;
 }
 
+// Phase A (starts) + selection for windows [w0, w0+wn) on stream st.  ev != nullptr: record the plan's
+// timing events around the kernels.
+static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool timed) {
+  abn_ctx* c = p->ctx;
+  const size_t N = (size_t)p->N, S = (size_t)p->S, o = (size_t)w0;
+  FitArgs a{};
+  fill_common(p, a);
+  a.p_uu += o;
+  a.eqp += o;
+  a.eqp_w += o;
+  a.D += o * N;
+  a.window_offset += (uint32_t)w0;
+  a.W = wn;
+  a.dmode = 0;
+  a.smode = 0;
+  a.simplex0 = p->simplexA.p + o * S * 20;
+  a.C = p->S;
+  a.max_iters = p->opt.max_iters_start;
+  a.best = p->bestA.p + o * S * 4;
+  a.info = p->infoA.p + o * S;
+  a.raw = nullptr;
+  if (timed) HIPCHK(c, hipEventRecord(p->ev[0], st));
+  // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once
+  const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && (long long)wn * p->S <= 2048 &&
+                    spec_applicable(a);
+  int rc = spec ? launch_fit_spec(c, a, st) : launch_fit(c, a, spec ? 64 : p->lanes_a, st);
+  if (rc) return rc;
+  if (timed) HIPCHK(c, hipEventRecord(p->ev[1], st));
+  SelectArgs s{};
+  s.tri = a.tri;
+  s.tid = a.tid;
+  s.N = a.N;
+  s.K = a.K;
+  s.T = a.T;
+  s.TP = a.TP;
+  s.p_uu = a.p_uu;
+  s.D = a.D;
+  s.models = a.best;
+  s.info = a.info;
+  s.W = wn;
+  s.S = p->S;
+  s.lse = p->lse.p + o * S;
+  s.model = p->model.p + o * 4;
+  s.pred = p->pred.p + o * N;
+  s.resid = p->resid.p + o * N;
+  s.best_start = p->best_start.p + o;
+  const size_t lds = ((size_t)9 * a.TP + p->topo.KP + kSelChunk) * sizeof(double);
+  if (timed) HIPCHK(c, hipEventRecord(p->ev[2], st));
+  hipLaunchKernelGGL(abn_select_kernel, dim3((unsigned)wn), dim3(kWave), lds, st, s);
+  HIPCHK(c, hipGetLastError());
+  if (timed) HIPCHK(c, hipEventRecord(p->ev[3], st));
+  return ABN_OK;
+}
+
+// Phase B (bootstraps) for windows [w0, w0+wn) on stream st
+static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool timed) {
+  abn_ctx* c = p->ctx;
+  const size_t N = (size_t)p->N, B = (size_t)p->B, o = (size_t)w0;
+  FitArgs a{};
+  fill_common(p, a);
+  a.p_uu += o;
+  a.eqp += o;
+  a.eqp_w += o;
+  a.pred += o * N;
+  a.resid += o * N;
+  a.idx += o * B * N;
+  a.model += o * 4;
+  a.window_offset += (uint32_t)w0;
+  a.W = wn;
+  a.dmode = 1;
+  a.smode = 1;
+  a.C = p->B;
+  a.max_iters = p->opt.max_iters_boot;
+  a.best = p->bestB.p + o * B * 4;
+  a.info = p->infoB.p + o * B;
+  a.raw = p->raw + o * B * 7;
+  if (timed) HIPCHK(c, hipEventRecord(p->ev[4], st));
+  if (p->stream_b) {  // gather the bootstrap observations once per fit, then stream them
+    double* dst = p->dstar.p + o * B * N;
+    const long long total = (long long)wn * p->B * p->N;
+    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 256LL * 64);
+    hipLaunchKernelGGL(abn_make_dstar_kernel, dim3(blocks), dim3(256), 0, st, dst, a.pred, a.resid, a.idx, p->N,
+                       (long long)p->B * p->N, total);
+    HIPCHK(c, hipGetLastError());
+    a.dmode = 2;
+    a.D = dst;
+  }
+  int rc = launch_fit(c, a, p->lanes, st);
+  if (rc) return rc;
+  if (timed) HIPCHK(c, hipEventRecord(p->ev[5], st));
+  return ABN_OK;
+}
+
 extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
   if (!p) return ABN_ERR_INVALID_ARG;
   abn_ctx* c = p->ctx;
@@ -741,46 +842,8 @@ extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
   HIPCHK(c, hipSetDevice(c->device));
   if (phase == 0) {
     if (p->S <= 0) return set_err(c, ABN_ERR_STATE, "plan has no starts");
-    FitArgs a{};
-    fill_common(p, a);
-    a.dmode = 0;
-    a.smode = 0;
-    a.simplex0 = p->simplexA.p;
-    a.C = p->S;
-    a.max_iters = p->opt.max_iters_start;
-    a.best = p->bestA.p;
-    a.info = p->infoA.p;
-    a.raw = nullptr;
-    HIPCHK(c, hipEventRecord(p->ev[0], c->stream));
-    // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once
-    const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && (long long)p->W * p->S <= 2048 &&
-                      spec_applicable(a);
-    int rc = spec ? launch_fit_spec(c, a) : launch_fit(c, a, p->lanes_a);
+    int rc = enqueue_phase_a(p, 0, p->W, c->stream, true);
     if (rc) return rc;
-    HIPCHK(c, hipEventRecord(p->ev[1], c->stream));
-    SelectArgs s{};
-    s.tri = a.tri;
-    s.tid = a.tid;
-    s.N = a.N;
-    s.K = a.K;
-    s.T = a.T;
-    s.TP = a.TP;
-    s.p_uu = p->p_uu.p;
-    s.D = p->D.p;
-    s.models = p->bestA.p;
-    s.info = p->infoA.p;
-    s.W = p->W;
-    s.S = p->S;
-    s.lse = p->lse.p;
-    s.model = p->model.p;
-    s.pred = p->pred.p;
-    s.resid = p->resid.p;
-    s.best_start = p->best_start.p;
-    const size_t lds = ((size_t)9 * a.TP + p->topo.KP + kSelChunk) * sizeof(double);
-    HIPCHK(c, hipEventRecord(p->ev[2], c->stream));
-    hipLaunchKernelGGL(abn_select_kernel, dim3((unsigned)p->W), dim3(kWave), lds, c->stream, s);
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(p->ev[3], c->stream));
     p->phase_a_done = true;
     p->ran_a = true;
     return ABN_OK;
@@ -788,41 +851,59 @@ extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
   if (phase == 1) {
     if (p->B <= 0) return set_err(c, ABN_ERR_STATE, "plan has no bootstraps");
     if (!p->phase_a_done) return set_err(c, ABN_ERR_STATE, "phase A has not run");
-    FitArgs a{};
-    fill_common(p, a);
-    a.dmode = 1;
-    a.smode = 1;
-    a.C = p->B;
-    a.max_iters = p->opt.max_iters_boot;
-    a.best = p->bestB.p;
-    a.info = p->infoB.p;
-    a.raw = p->raw;
-    HIPCHK(c, hipEventRecord(p->ev[4], c->stream));
-    if (p->stream_b) {  // gather the bootstrap observations once per fit, then stream them
-      const long long total = (long long)p->W * p->B * p->N;
-      const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 256LL * 64);
-      hipLaunchKernelGGL(abn_make_dstar_kernel, dim3(blocks), dim3(256), 0, c->stream, p->dstar.p, p->pred.p,
-                         p->resid.p, p->idx.p, p->N, (long long)p->B * p->N, total);
-      HIPCHK(c, hipGetLastError());
-      a.dmode = 2;
-      a.D = p->dstar.p;
-    }
-    int rc = launch_fit(c, a, p->lanes);
+    int rc = enqueue_phase_b(p, 0, p->W, c->stream, true);
     if (rc) return rc;
-    HIPCHK(c, hipEventRecord(p->ev[5], c->stream));
     p->ran_b = true;
     return ABN_OK;
   }
   return set_err(c, ABN_ERR_INVALID_ARG, "phase must be 0 or 1");
 }
 
+// Whole pass.  opts.window_groups > 1 cuts the plan into contiguous window groups that run A -> select -> B
+// on their own HIP streams (a window's bootstraps need only that window's starts), forking from and joining
+// back into the context's stream with events; results do not depend on the grouping and timing events are
+// recorded for group 0.  Measured on MI355X / ROCm 7.2 (scripts/groups_bench.py, C4 shard): the groups'
+// kernels did not overlap (23 ms with 1 group, 43 ms with 8), so the default is ONE group.
 extern "C" int abn_plan_run(abn_plan* p) {
   if (!p) return ABN_ERR_INVALID_ARG;
-  int rc = ABN_OK;
-  if (p->S > 0) rc = abn_plan_run_phase(p, 0);
-  if (rc) return rc;
-  if (p->B > 0) rc = abn_plan_run_phase(p, 1);
-  return rc;
+  abn_ctx* c = p->ctx;
+  if (!p->windows_set) return set_err(c, ABN_ERR_STATE, "abn_plan_set_windows has not been called");
+  int groups = p->opt.window_groups > 0 ? p->opt.window_groups : 1;
+  groups = std::max(1, std::min(groups, p->W));
+  if (groups == 1 || p->S <= 0 || p->B <= 0) {
+    int rc = ABN_OK;
+    if (p->S > 0) rc = abn_plan_run_phase(p, 0);
+    if (rc) return rc;
+    if (p->B > 0) rc = abn_plan_run_phase(p, 1);
+    return rc;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  while ((int)c->side.size() < groups) {
+    hipStream_t st = nullptr;
+    HIPCHK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    c->side.push_back(st);
+  }
+  if (!p->ev_fork) HIPCHK(c, hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+  while ((int)p->ev_join.size() < groups) {
+    hipEvent_t e = nullptr;
+    HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    p->ev_join.push_back(e);
+  }
+  HIPCHK(c, hipEventRecord(p->ev_fork, c->stream));
+  for (int g = 0; g < groups; ++g) {
+    const int w0 = (int)((long long)p->W * g / groups), w1 = (int)((long long)p->W * (g + 1) / groups);
+    hipStream_t st = c->side[(size_t)g];
+    HIPCHK(c, hipStreamWaitEvent(st, p->ev_fork, 0));
+    int rc = enqueue_phase_a(p, w0, w1 - w0, st, g == 0);
+    if (!rc) rc = enqueue_phase_b(p, w0, w1 - w0, st, g == 0);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(p->ev_join[(size_t)g], st));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, p->ev_join[(size_t)g], 0));
+  }
+  p->phase_a_done = true;
+  p->ran_a = true;
+  p->ran_b = true;
+  return ABN_OK;
 }
 
 extern "C" int abn_plan_sync(abn_plan* p) {
@@ -923,7 +1004,7 @@ extern "C" int abn_plan_debug_stamps(abn_plan* p, unsigned long long* out8) {
   a.info = p->infoA.p;
   a.raw = nullptr;
   a.dbg = d.p;
-  int rc = launch_fit(c, a, p->lanes);
+  int rc = launch_fit(c, a, p->lanes, c->stream);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(out8, d.p, 64, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -58,6 +58,10 @@ typedef struct abn_options {
                                            (gathered once per fit, 8 B/row/evaluation); 1 = re-stream the u32
                                            index row and gather residuals every evaluation (4 B/row + gather) */
   double sd_tolerance;                  /* f64::EPSILON (argmin default, never overridden)             */
+  int32_t window_groups;                /* abn_plan_run: windows are cut into this many groups that run
+                                           A -> select -> B concurrently on separate HIP streams
+                                           (0 or 1 = one stream, the default: no gain measured)                    */
+  int32_t reserved1;
 } abn_options;
 
 typedef struct abn_fit_info {

@@ -27,7 +27,7 @@ def test_header_symbols_are_exported(abn):
 
 def test_options_layout_and_defaults(abn):
     o = abn.default_options()
-    assert ctypes.sizeof(abn.Options) == 40
+    assert ctypes.sizeof(abn.Options) == 48
     assert o.seed == 20260101 and o.lanes_per_chain == 0 and o.strict_order == 0
     assert o.max_iters_start == 10000 and o.max_iters_boot == 1000   # src/ab_neutral.rs:62, src/boot_model.rs:81
     assert o.sd_tolerance == np.finfo(np.float64).eps

@@ -219,7 +219,7 @@ def test_plan_multi_window_matches_per_window_runs(abn, gpu_ctx, golden, oracle)
     W, S, B, seed = 3, 4, 12, 77
     D = np.abs(ped[:, 3][None, :] * rng.uniform(0.8, 1.2, (W, 1)) + rng.normal(0, 1e-4, (W, n)))
     p0 = np.array([0.99, 0.985, 0.992])
-    o = abn.default_options(seed=seed, lanes_per_chain=16)
+    o = abn.default_options(seed=seed, lanes_per_chain=16, window_groups=2)   # two concurrent window groups
     plan = abn.Plan(gpu_ctx, ped[:, :3], W, S, B, options=o)
     plan.set_windows(D, p0)
     plan.run()
