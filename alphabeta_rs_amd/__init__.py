@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "abn_default_options", "abn_device_count", "abn_init", "abn_shutdown", "abn_last_error",
     "abn_status_string", "abn_version", "abn_cost_batch", "abn_fit_batch", "abn_gen_start_simplices",
     "abn_gen_boot_simplices", "abn_gen_boot_indices", "abn_ab_neutral_run", "abn_boot_model_run",
-    "abn_analyze", "abn_select_best", "abn_bootstrap_rows", "abn_plan_create", "abn_plan_destroy", "abn_plan_set_windows", "abn_plan_run",
+    "abn_analyze", "abn_select_best", "abn_bootstrap_rows", "abn_pairwise_divergence", "abn_plan_create", "abn_plan_destroy", "abn_plan_set_windows", "abn_plan_run",
     "abn_plan_run_phase", "abn_plan_sync", "abn_plan_kernel_ms", "abn_plan_raw_device_ptr",
     "abn_plan_bind_raw", "abn_plan_download", "abn_plan_counters", "abn_plan_device_bytes",
 ]
@@ -109,6 +109,8 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     L.abn_analyze.argtypes = [dp, C.c_int64, dp]
     L.abn_select_best.argtypes = [vp, dp, C.c_int32, C.c_double, dp, C.c_int32, C.POINTER(C.c_int32), dp, dp, dp, dp]
     L.abn_bootstrap_rows.argtypes = [vp, dp, C.c_int64, dp]
+    L.abn_pairwise_divergence.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int32, C.c_int64, C.POINTER(C.c_uint64),
+                                          C.POINTER(C.c_uint64), dp]
     L.abn_plan_create.argtypes = [vp, op, dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,
                                   C.POINTER(vp)]
     L.abn_plan_destroy.argtypes = [vp]
@@ -290,6 +292,19 @@ class Context:
         raw = np.empty((b.shape[0], 7))
         self._check(self._L.abn_bootstrap_rows(self._h, _dp(b), b.shape[0], _dp(raw)))
         return raw
+
+    def pairwise_divergence(self, codes):
+        """DMatrix::from (src/pedigree.rs:210-261).  codes: (n_samples, n_sites) u8 = status | 0x80 if filtered.
+        Returns (diff u64, both u64, dvalue f64), one entry per pair i < j in nested-loop order."""
+        codes = np.ascontiguousarray(codes, dtype=np.uint8)
+        n, L = codes.shape
+        npairs = n * (n - 1) // 2
+        diff, both = np.zeros(npairs, dtype=np.uint64), np.zeros(npairs, dtype=np.uint64)
+        dval = np.zeros(npairs)
+        self._check(self._L.abn_pairwise_divergence(self._h, codes.ctypes.data_as(C.POINTER(C.c_uint8)), n, L,
+                                                    diff.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                    both.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(dval)))
+        return diff, both, dval
 
     # ---- (3) boot_model::run
     def boot_model_run(self, pedigree, model, pred, resid, p0uu, eqp, eqp_weight, n_boot, *,

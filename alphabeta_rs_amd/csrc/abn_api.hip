@@ -1169,6 +1169,51 @@ extern "C" int abn_bootstrap_rows(abn_ctx* c, const double* best, int64_t n_boot
 }
 
 // ------------------------------------------------------------------------------------------------
+// pedigree construction: pairwise divergence (src/pedigree.rs:210-261)
+// ------------------------------------------------------------------------------------------------
+extern "C" int abn_pairwise_divergence(abn_ctx* c, const uint8_t* codes, int32_t n_samples, int64_t n_sites,
+                                       uint64_t* diff, uint64_t* both, double* dvalue) {
+  if (!c) return ABN_ERR_INVALID_ARG;
+  if (!codes || n_samples <= 0 || n_sites < 0) return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
+  const size_t n = (size_t)n_samples, npairs = n * (n - 1) / 2;
+  if (npairs == 0) return ABN_OK;
+  // tile: as many sites as fit 128 KiB of LDS for all samples, a multiple of 64, at most kPairTileMax
+  int tile_sites = (int)std::min<size_t>((size_t)kPairTileMax, ((size_t)128 * 1024 / n) & ~(size_t)63);
+  if (tile_sites < 64) return set_err(c, ABN_ERR_INVALID_ARG, "too many samples for one LDS tile (max 2048)");
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf<uint8_t> dcodes;
+  DevBuf<unsigned long long> ddiff, dboth;
+  HIPCHK(c, dcodes.alloc(std::max<size_t>(n * (size_t)n_sites, 4)));
+  HIPCHK(c, ddiff.alloc(npairs));
+  HIPCHK(c, dboth.alloc(npairs));
+  if (n_sites > 0)
+    HIPCHK(c, hipMemcpyAsync(dcodes.p, codes, n * (size_t)n_sites, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(ddiff.p, 0, ddiff.bytes(), c->stream));
+  HIPCHK(c, hipMemsetAsync(dboth.p, 0, dboth.bytes(), c->stream));
+  if (n_sites > 0) {
+    const size_t lds = n * (size_t)tile_sites;
+    if (lds > 64 * 1024)
+      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(abn_pairwise_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long long ntiles = ((long long)n_sites + tile_sites - 1) / tile_sites;
+    const unsigned blocks = (unsigned)std::min<long long>(ntiles, 256LL * 4);
+    hipLaunchKernelGGL(abn_pairwise_kernel, dim3(blocks), dim3(256), lds, c->stream, dcodes.p, n_samples,
+                       (long long)n_sites, tile_sites, ddiff.p, dboth.p);
+    HIPCHK(c, hipGetLastError());
+  }
+  std::vector<unsigned long long> hd(npairs), hb(npairs);
+  HIPCHK(c, hipMemcpyAsync(hd.data(), ddiff.p, ddiff.bytes(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(hb.data(), dboth.p, dboth.bytes(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t p = 0; p < npairs; ++p) {
+    if (diff) diff[p] = hd[p];
+    if (both) both[p] = hb[p];
+    if (dvalue) dvalue[p] = (double)hd[p] / (2.0 * (double)hb[p]);  // src/pedigree.rs:257
+  }
+  return ABN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // src/analysis.rs:50-98 on the host (ndarray mean / Welford std with mul_add, ndarray-stats Linear CI)
 // ------------------------------------------------------------------------------------------------
 extern "C" int abn_analyze(const double* raw, int64_t n_boot, double* out32) {

@@ -1154,6 +1154,67 @@ __global__ __launch_bounds__(kWave) void abn_cost_kernel(const CostArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pairwise divergence, DMatrix::from (src/pedigree.rs:210-261): byte/integer work, one pass over the codes.
+// A workgroup stages a tile of up to kPairTileMax sites of ALL samples in LDS (coalesced 16-byte loads), then every
+// thread owns pairs (i, j) and walks the tile four sites at a time: both-valid mask from the 0x80 flags,
+// v_sad_u8 for the sum of |status_i - status_j|, popcount for the number of compared sites.  Per-pair tile sums
+// go to global u64 accumulators with integer atomics (exact and order-independent).
+// ------------------------------------------------------------------------------------------------
+constexpr int kPairTileMax = 2048;  // sites per tile (bytes per sample and tile), shrunk for many samples
+
+__global__ __launch_bounds__(256) void abn_pairwise_kernel(const uint8_t* codes, int n, long long L, int tile_sites,
+                                                           unsigned long long* diff, unsigned long long* both) {
+  extern __shared__ __align__(16) uint32_t tile[];  // [n][tile_sites/4]
+  const int tid = threadIdx.x;
+  const long long ntiles = (L + tile_sites - 1) / tile_sites;
+  const int npairs = n * (n - 1) / 2;
+  const int WPT = tile_sites / 4;  // words per sample and tile
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long long s0 = t * tile_sites;
+    const int len = (int)((L - s0) < tile_sites ? (L - s0) : tile_sites);
+    __syncthreads();
+    // stage: sites beyond the end of the data are marked invalid (0x80)
+    for (int w = tid; w < n * WPT; w += blockDim.x) {
+      const int smp = w / WPT, k = w - smp * WPT;
+      const uint8_t* src = codes + (size_t)smp * (size_t)L + (size_t)s0 + (size_t)k * 4;
+      uint32_t v = 0x80808080u;
+      if (k * 4 + 3 < len && ((((size_t)smp * (size_t)L + (size_t)s0) & 3) == 0)) {
+        v = *reinterpret_cast<const uint32_t*>(src);
+      } else {
+        v = 0;
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t b = (k * 4 + e < len) ? src[e] : 0x80u;
+          v |= b << (8 * e);
+        }
+      }
+      tile[w] = v;
+    }
+    __syncthreads();
+    for (int p = tid; p < npairs; p += blockDim.x) {
+      // pair index -> (i, j), the nested loop order of src/pedigree.rs:214-215
+      int i = 0, rem = p;
+      while (rem >= n - 1 - i) {
+        rem -= n - 1 - i;
+        ++i;
+      }
+      const int j = i + 1 + rem;
+      const uint32_t* a = tile + i * WPT;
+      const uint32_t* b = tile + j * WPT;
+      uint32_t d = 0, c = 0;
+      for (int k = 0; k < WPT; ++k) {
+        const uint32_t x = a[k], y = b[k];
+        const uint32_t ok = ~(x | y) & 0x80808080u;          // top bit set where both sites are valid
+        const uint32_t m = (ok >> 7) * 0xFFu;                  // 0xFF per valid byte
+        d = __builtin_amdgcn_sad_u8(x & m & 0x03030303u, y & m & 0x03030303u, d);  // :253 abs_diff
+        c += (uint32_t)__builtin_popcount(ok);                 // :254 compared_sites
+      }
+      if (d) atomicAdd(&diff[p], (unsigned long long)d);
+      if (c) atomicAdd(&both[p], (unsigned long long)c);
+    }
+  }
+}
+
 // src/boot_model.rs:86-91 for a batch of fitted vectors (abn_bootstrap_rows)
 __global__ __launch_bounds__(256) void abn_rows_kernel(const double* best, long long n, double* raw) {
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {

@@ -237,9 +237,10 @@ class Pedigree {  // src/pedigree.rs:44-45
       f << fmt_f64(at(i, 0)) << "\t" << fmt_f64(at(i, 1)) << "\t" << fmt_f64(at(i, 2)) << "\t" << fmt_f64(at(i, 3)) << "\n";
   }
 
-  // src/pedigree.rs:92-193; defined in pedigree_build.hpp
+  // src/pedigree.rs:92-193; defined in pedigree_build.hpp.  gpu_pairwise: the O(pairs x sites) status
+  // comparison (DMatrix::from, :210-261) runs on the MI355X (abn_pairwise_divergence); same bits either way.
   static std::pair<Pedigree, double> build(const std::string& nodelist, const std::string& edgelist,
-                                           double posterior_max_filter);
+                                           double posterior_max_filter, bool gpu_pairwise = false);
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -337,7 +338,7 @@ namespace alphabeta {
 // src/alphabeta.rs:23-59
 inline RunResult run(const Args& args) {
   std::printf("Building pedigree...\n");
-  auto [pedigree, p0uu] = Pedigree::build(args.nodes, args.edges, args.posterior_max_filter);
+  auto [pedigree, p0uu] = Pedigree::build(args.nodes, args.edges, args.posterior_max_filter, /*gpu_pairwise=*/true);
   return run_on_pedigree(std::move(pedigree), p0uu, args.iterations, args.output);
 }
 }  // namespace alphabeta

@@ -106,7 +106,7 @@ inline std::string read_file(const std::string& path, const char* what) {
 }  // namespace detail
 
 inline std::pair<Pedigree, double> Pedigree::build(const std::string& nodelist, const std::string& edgelist,
-                                                   double posterior_max_filter) {
+                                                   double posterior_max_filter, bool gpu_pairwise) {
   using namespace detail;
   const std::string nodes_txt = read_file(nodelist, "nodelist"), edges_txt = read_file(edgelist, "edgelist");
   // :98-117
@@ -167,23 +167,42 @@ inline std::pair<Pedigree, double> Pedigree::build(const std::string& nodelist, 
   // DMatrix::from, :210-261 — entry [i][j - i - 1]
   const size_t nn = nodes.size();
   std::vector<double> dm(nn * nn, 0.0);
-  for (size_t i = 0; i < nn; ++i)
-    for (size_t j = i + 1; j < nn; ++j) {
-      const auto &a = nodes[i].sites, &b = nodes[j].sites;
-      if (a.size() != b.size()) {
-        std::printf("Lengths do not match, all bets are off: %zu vs %zu\n", a.size(), b.size());
-        dm[i * nn + (j - i - 1)] = 0.0;
-        continue;
+  bool same_len = true;
+  for (size_t i = 1; i < nn; ++i) same_len = same_len && nodes[i].sites.size() == nodes[0].sites.size();
+  if (gpu_pairwise && same_len && nn >= 2) {
+    // one byte per (sample, site): status | 0x80 when the posterior is below the filter
+    const size_t L = nodes[0].sites.size();
+    std::vector<uint8_t> codes(nn * L);
+    for (size_t i = 0; i < nn; ++i)
+      for (size_t k = 0; k < L; ++k)
+        codes[i * L + k] = (uint8_t)(nodes[i].sites[k].status_numeric |
+                                     (nodes[i].sites[k].posteriormax < posterior_max_filter ? 0x80u : 0u));
+    std::vector<double> dv(nn * (nn - 1) / 2);
+    Device& dev = default_device();
+    dev.check(abn_pairwise_divergence(dev.get(), codes.data(), (int32_t)nn, (int64_t)L, nullptr, nullptr, dv.data()),
+              "Pedigree::build (pairwise divergence)");
+    size_t p = 0;
+    for (size_t i = 0; i < nn; ++i)
+      for (size_t j = i + 1; j < nn; ++j) dm[i * nn + (j - i - 1)] = dv[p++];
+  } else {
+    for (size_t i = 0; i < nn; ++i)
+      for (size_t j = i + 1; j < nn; ++j) {
+        const auto &a = nodes[i].sites, &b = nodes[j].sites;
+        if (a.size() != b.size()) {
+          std::printf("Lengths do not match, all bets are off: %zu vs %zu\n", a.size(), b.size());
+          dm[i * nn + (j - i - 1)] = 0.0;
+          continue;
+        }
+        uint64_t div = 0, compared = 0;
+        for (size_t k = 0; k < a.size(); ++k) {
+          if (a[k].posteriormax < posterior_max_filter || b[k].posteriormax < posterior_max_filter) continue;
+          div += a[k].status_numeric > b[k].status_numeric ? a[k].status_numeric - b[k].status_numeric
+                                                           : b[k].status_numeric - a[k].status_numeric;
+          ++compared;
+        }
+        dm[i * nn + (j - i - 1)] = (double)div / (2.0 * (double)compared);
       }
-      uint64_t div = 0, compared = 0;
-      for (size_t k = 0; k < a.size(); ++k) {
-        if (a[k].posteriormax < posterior_max_filter || b[k].posteriormax < posterior_max_filter) continue;
-        div += a[k].status_numeric > b[k].status_numeric ? a[k].status_numeric - b[k].status_numeric
-                                                         : b[k].status_numeric - a[k].status_numeric;
-        ++compared;
-      }
-      dm[i * nn + (j - i - 1)] = (double)div / (2.0 * (double)compared);
-    }
+  }
 
   // DMatrix::convert, :263-337 — undirected graph, edge weight = |generation difference|
   size_t vmax = 0;

@@ -148,6 +148,18 @@ int abn_boot_model_run(abn_ctx* ctx, const abn_options* opts, const double* pedi
  * alpha, beta, beta/alpha, weight, intercept, pr_mm, pr_um, pr_uu (struct Analysis, :15-47). */
 int abn_analyze(const double* raw, int64_t n_boot, double* out32);
 
+/* ------------------------------------------------------------------ pedigree construction
+ * DMatrix::from (src/pedigree.rs:210-261): pairwise divergence of n samples over n_sites aligned sites.
+ *   codes[n x n_sites] (u8, row per sample): status_numeric 0 = U, 1 = I, 2 = M
+ *   (src/methylation_site.rs:130-136), plus 0x80 when the site's posteriormax is below the filter (the
+ *   site is then skipped for every pair it takes part in, src/pedigree.rs:249-251).
+ * Outputs per unordered pair i < j at index p = i*n - i*(i+1)/2 + (j - i - 1) (the nested-loop order of
+ * :214-215):  diff[p] = sum of |status_i - status_j| over sites valid in both (:253),  both[p] = number of
+ * such sites (:254),  dvalue[p] = diff / (2 * both) in f64 (:257; NaN for both == 0 like the reference's
+ * 0/0).  Integer sums are exact, so the result does not depend on the device's summation order. */
+int abn_pairwise_divergence(abn_ctx* ctx, const uint8_t* codes, int32_t n_samples, int64_t n_sites,
+                            uint64_t* diff, uint64_t* both, double* dvalue);
+
 /* ------------------------------------------------------------------ (4) batched, device-resident plan
  * One pedigree topology (t0,t1,t2 of N rows), W windows that differ in D / p0uu (the metaprofile loop,
  * src/cli/metaprofile.rs:50-72, where every window shares nodelist/edgelist), S starts and B bootstraps

@@ -93,6 +93,8 @@ def lib() -> C.CDLL:
                                      C.c_uint32, C.c_uint32, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int,
                                      C.c_int, C.c_int, dp, C.c_void_p]
         L.abo_analyze.argtypes = [dp, C.c_int64, dp]
+        L.abo_pairwise_divergence.argtypes = [C.POINTER(C.c_uint8), dp, C.c_int, C.c_int64, C.c_double,
+                                              C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), dp]
         L.abo_max_threads.restype = C.c_int
         _lib = L
     return _lib
@@ -231,6 +233,19 @@ def analyze(raw):
     out = np.empty(32)
     lib().abo_analyze(_dp(raw), raw.shape[0], _dp(out))
     return out.reshape(4, 8)
+
+
+def pairwise_divergence(status, posteriormax, posterior_max_filter):
+    """DMatrix::from (src/pedigree.rs:210-261): (diff, both, dvalue) per pair i < j."""
+    st = np.ascontiguousarray(status, dtype=np.uint8)
+    pm = _f64(posteriormax)
+    n, L_ = st.shape
+    npairs = n * (n - 1) // 2
+    diff, both, dval = np.zeros(npairs, dtype=np.uint64), np.zeros(npairs, dtype=np.uint64), np.zeros(npairs)
+    lib().abo_pairwise_divergence(st.ctypes.data_as(C.POINTER(C.c_uint8)), _dp(pm), n, L_, posterior_max_filter,
+                                  diff.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                  both.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(dval))
+    return diff, both, dval
 
 
 def max_threads():

@@ -643,6 +643,31 @@ void abo_analyze(const double* raw, int64_t b, double out[32]) {
   free(ratio);
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * DMatrix::from, src/pedigree.rs:210-261: for every pair i < j (nested-loop order) the sum of
+ * |status_i - status_j| over sites whose posteriormax passes the filter in BOTH samples (:249-253), the
+ * number of such sites (:254) and D = divergence / (2 * compared_sites) (:257).
+ * status[n*L] in {0,1,2} (status_numeric), posteriormax[n*L] doubles.
+ * ---------------------------------------------------------------------------------------------- */
+void abo_pairwise_divergence(const uint8_t* status, const double* posteriormax, int n, int64_t n_sites,
+                             double posterior_max_filter, uint64_t* diff, uint64_t* both, double* dvalue) {
+  int64_t p = 0;
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j, ++p) {
+      uint64_t divergence = 0, compared = 0;
+      for (int64_t k = 0; k < n_sites; ++k) {
+        const double fp = posteriormax[(int64_t)i * n_sites + k], sp = posteriormax[(int64_t)j * n_sites + k];
+        if (fp < posterior_max_filter || sp < posterior_max_filter) continue;
+        const int a = status[(int64_t)i * n_sites + k], b = status[(int64_t)j * n_sites + k];
+        divergence += (uint64_t)(a > b ? a - b : b - a);
+        compared += 1;
+      }
+      if (diff) diff[p] = divergence;
+      if (both) both[p] = compared;
+      if (dvalue) dvalue[p] = (double)divergence / (2.0 * (double)compared);
+    }
+}
+
 int abo_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

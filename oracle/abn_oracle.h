@@ -130,6 +130,10 @@ void abo_boot_model(const double* ped, int n, const double model[4], const doubl
  * mean[8] (alpha,beta,beta/alpha,weight,intercept,pr_mm,pr_um,pr_uu), sd[8], ci_lo[8], ci_hi[8] -> 32 */
 void abo_analyze(const double* raw, int64_t b, double out[32]);
 
+/* DMatrix::from, src/pedigree.rs:210-261 (pairs in nested-loop order i < j) */
+void abo_pairwise_divergence(const uint8_t* status, const double* posteriormax, int n, int64_t n_sites,
+                             double posterior_max_filter, uint64_t* diff, uint64_t* both, double* dvalue);
+
 int abo_max_threads(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,73 @@
+"""DMatrix::from (src/pedigree.rs:210-261), SURVEY.md §8f row 1: oracle against the reference's bundled
+methylomes (data/methylome/*.txt -> the D column of data/pedigree_generated.txt), and the HIP kernel
+(abn_pairwise_divergence) against the oracle, bit-exact (integer sums, one f64 division)."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+STATUS = {"U": 0, "I": 1, "M": 2}
+
+
+def load_methylome(path):
+    """the CG rows of a methylome file as (status_numeric, posteriormax): first/second format of
+    src/methylation_site.rs:146-232"""
+    st, pm = [], []
+    for ln in path.read_text().splitlines():
+        f = ln.split("\t")
+        if len(f) in (9, 10) and f[3] == "CG":
+            st.append(STATUS.get(f[7][0], 0))
+            pm.append(float(f[6]))
+    return np.array(st, dtype=np.uint8), np.array(pm)
+
+
+def bundled_samples():
+    files = ["G0.txt", "G1_2.txt", "G4_2.txt", "G4_8.txt"]          # the "Y" rows of data/nodelist.txt, in order
+    cols = [load_methylome(GOLDEN / "data" / "methylome" / f) for f in files]
+    return np.stack([c[0] for c in cols]), np.stack([c[1] for c in cols])
+
+
+def test_oracle_pairwise_reproduces_generated_pedigree(oracle, golden):
+    status, pmax = bundled_samples()
+    assert status.shape == (4, 500)
+    diff, both, dval = oracle.pairwise_divergence(status, pmax, 0.99)
+    assert np.array_equal(dval, golden["generated"][:, 3])      # D.value column, pair order of src/pedigree.rs:273-274
+    assert np.all(both > 0) and np.all(diff <= 2 * both)
+
+
+def _codes(status, pmax, flt):
+    return (status | np.where(pmax < flt, 0x80, 0)).astype(np.uint8)
+
+
+@pytest.mark.gpu
+def test_gpu_pairwise_bundled_methylomes(abn, gpu_ctx, oracle, golden):
+    status, pmax = bundled_samples()
+    diff, both, dval = gpu_ctx.pairwise_divergence(_codes(status, pmax, 0.99))
+    wd, wb, wv = oracle.pairwise_divergence(status, pmax, 0.99)
+    assert np.array_equal(diff, wd) and np.array_equal(both, wb) and np.array_equal(dval, wv)
+    assert np.array_equal(dval, golden["generated"][:, 3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,L", [(2, 1), (2, 5), (3, 2047), (15, 2048), (15, 2049), (7, 100003), (70, 4100),
+                                 (130, 1500)])
+def test_gpu_pairwise_random(abn, gpu_ctx, oracle, n, L):
+    rng = np.random.default_rng(n * 1000 + L)
+    status = rng.integers(0, 3, size=(n, L), dtype=np.uint8)
+    pmax = rng.uniform(0.9, 1.0, size=(n, L))
+    pmax[0, : L // 2] = 0.5                      # a sample with a long filtered stretch
+    if n > 2:
+        pmax[2] = 0.1                            # a sample with no valid site at all -> 0/0 = NaN like the reference
+    diff, both, dval = gpu_ctx.pairwise_divergence(_codes(status, pmax, 0.99))
+    wd, wb, wv = oracle.pairwise_divergence(status, pmax, 0.99)
+    assert np.array_equal(diff, wd) and np.array_equal(both, wb)
+    assert np.array_equal(dval, wv, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_gpu_pairwise_degenerate(abn, gpu_ctx):
+    d, b, v = gpu_ctx.pairwise_divergence(np.zeros((1, 10), dtype=np.uint8))   # one sample: no pairs
+    assert d.size == 0
+    d, b, v = gpu_ctx.pairwise_divergence(np.zeros((3, 0), dtype=np.uint8))    # no sites: 0/0
+    assert np.all(b == 0) and np.all(np.isnan(v))
