@@ -448,3 +448,52 @@ def test_invalid_arguments_are_status_codes(abn, gpu_ctx, golden):
     plan.close()
     # zero candidates / fits are fine
     assert gpu_ctx.cost_batch(ped, 0.7, 0.7, 1.0, np.zeros((0, 4))).shape == (0,)
+
+
+def test_full_size_properties_c2_and_c4(abn, gpu_ctx, golden, oracle):
+    """BASELINE C2 (bundled pedigree x 1000 bootstraps) and a C4 shard (25 windows x 1000 bootstraps) at
+    full size: shard-independence (two half-shards of the bootstraps equal the whole, bit for bit),
+    idempotence, and sampled windows / bootstraps bit-equal to the oracle."""
+    from alphabeta_rs_amd import synthetic
+
+    # ---- C2
+    ped, p0 = golden["generated"], golden["p0uu_generated"]
+    o = abn.default_options(seed=20260101)
+    whole = abn.Plan(gpu_ctx, ped[:, :3], 1, 10, 1000, options=o)
+    whole.set_windows(ped[:, 3][None, :], np.array([p0]))
+    whole.run()
+    a = whole.download()
+    halves = []
+    for b0 in (0, 500):
+        h = abn.Plan(gpu_ctx, ped[:, :3], 1, 10, 500, boot_offset=b0, options=o)
+        h.set_windows(ped[:, 3][None, :], np.array([p0]))
+        h.run()
+        halves.append(h.download()["raw"][0])
+        h.close()
+    assert np.array_equal(np.concatenate(halves), a["raw"][0])
+    lb = int(a["info_b"]["lanes"][0, 0])
+    wraw, _ = oracle.boot_model(ped, a["models"][0], a["pred"][0], a["resid"][0], p0, p0, 1.0, 20260101, 0, 990, 10,
+                                lanes=lb)
+    assert np.array_equal(a["raw"][0, 990:], wraw)
+    whole.close()
+
+    # ---- C4 shard
+    gens, D, p0w, _ = synthetic.c4_windows(25)
+    plan = abn.Plan(gpu_ctx, gens, 25, 10, 1000, options=o)
+    plan.set_windows(D, p0w)
+    plan.run()
+    r1 = plan.download()
+    plan.run()
+    r2 = plan.download()
+    assert np.array_equal(r1["raw"], r2["raw"], equal_nan=True) and np.array_equal(r1["best_start"], r2["best_start"])
+    assert np.all(r1["best_start"] >= 0)
+    la, lb = int(r1["info_a"]["lanes"][0, 0]), int(r1["info_b"]["lanes"][0, 0])
+    for w in (0, 13, 24):
+        pw = np.concatenate([gens, D[w][:, None]], axis=1)
+        s0 = abn.gen_start_simplices(20260101, w, 10, D[w].max())
+        fits = oracle.fit_batch(pw, p0w[w], p0w[w], 1.0, s0, 10000, lanes=la)
+        k, model, pred, resid, _ = oracle.select_best(pw, p0w[w], fits["best"])
+        assert r1["best_start"][w] == k and np.array_equal(r1["models"][w], model)
+        wraw, _ = oracle.boot_model(pw, model, pred, resid, p0w[w], p0w[w], 1.0, 20260101, w, 500, 8, lanes=lb)
+        assert np.array_equal(r1["raw"][w, 500:508], wraw)
+    plan.close()
