@@ -53,6 +53,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
 
 HOST = PKG / "host"
 CLI = PKG / "bin" / "alphabeta"
+META_CLI = PKG / "bin" / "metaprofile_alphabeta"
 PEDIGREE_LIB = PKG / "libabneutral_host.so"
 
 
@@ -60,12 +61,19 @@ def build_host(force: bool = False, verbose: bool = False) -> Path:
     """The C++ host layer: the `alphabeta` CLI (reference flags and output files) and a small shared
     library exposing Pedigree::build to the tests.  Both link libabneutral_hip.so via $ORIGIN rpaths."""
     build_hip()
-    srcs = [HOST / "alphabeta_cli.cpp", HOST / "alphabeta.hpp", HOST / "pedigree_build.hpp", HOST / "host_capi.cpp"]
+    srcs = [HOST / "alphabeta_cli.cpp", HOST / "alphabeta.hpp", HOST / "pedigree_build.hpp", HOST / "host_capi.cpp",
+            HOST / "metaprofile.hpp", HOST / "metaprofile_cli.cpp"]
     newest = max(p.stat().st_mtime for p in srcs)
     CLI.parent.mkdir(exist_ok=True)
     common = ["-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-I", str(PKG.parent / "include")]
     if force or not CLI.exists() or CLI.stat().st_mtime < newest:
         cmd = [hipcc_path(), *common, "-o", str(CLI), str(HOST / "alphabeta_cli.cpp"), "-L", str(PKG),
+               "-labneutral_hip", "-Wl,-rpath,$ORIGIN/.."]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=str(PKG))
+    if force or not META_CLI.exists() or META_CLI.stat().st_mtime < newest:
+        cmd = [hipcc_path(), *common, "-o", str(META_CLI), str(HOST / "metaprofile_cli.cpp"), "-L", str(PKG),
                "-labneutral_hip", "-Wl,-rpath,$ORIGIN/.."]
         if verbose:
             print(" ".join(cmd))

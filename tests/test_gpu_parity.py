@@ -497,3 +497,46 @@ def test_full_size_properties_c2_and_c4(abn, gpu_ctx, golden, oracle):
         wraw, _ = oracle.boot_model(pw, model, pred, resid, p0w[w], p0w[w], 1.0, 20260101, w, 500, 8, lanes=lb)
         assert np.array_equal(r1["raw"][w, 500:508], wraw)
     plan.close()
+
+
+def test_metaprofile_batch_driver(abn, gpu_ctx, golden, oracle, tmp_path):
+    """`metaprofile_alphabeta` (src/cli/metaprofile.rs:33-114): window directories as src/setup.rs writes them,
+    all windows fitted by one batched plan; results.txt and the (iterations, 7, windows) raw.npy against
+    per-window oracle runs.  A window without its nodelist is reported and skipped like :64-65."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    from alphabeta_rs_amd import build as B
+
+    B.build_host()
+    gold = Path(__file__).resolve().parent / "golden"
+    dirs = [(r, w) for r in ("upstream", "gene", "downstream") for w in (0, 50)]
+    for r, w in dirs:
+        d = tmp_path / r / str(w)
+        d.mkdir(parents=True)
+        if (r, w) != ("downstream", 50):
+            shutil.copy(gold / "data" / "nodelist.txt", d / "nodelist.txt")
+            shutil.copy(gold / "data" / "edgelist.txt", d / "edgelist.txt")
+    iters, seed = 8, 123
+    r = subprocess.run([str(B.META_CLI), "-o", str(tmp_path), "--name", "t", "-s", "50", "--iterations", str(iters),
+                        "--seed", str(seed)], capture_output=True, text=True, cwd=str(gold))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Error: Error while building pedigree" in r.stdout           # the missing window
+    raw = np.load(tmp_path / "raw.npy")
+    assert raw.shape == (iters, 7, 5)
+    lines = (tmp_path / "results.txt").read_text().splitlines()
+    assert lines[0].startswith("run;window;cg_count;region;alpha;beta") and len(lines) == 1 + 5
+    ped, p0 = golden["generated"], golden["p0uu_generated"]
+    for w in range(5):
+        s0 = abn.gen_start_simplices(seed, w, iters, ped[:, 3].max())
+        fits = oracle.fit_batch(ped, p0, p0, 1.0, s0, 10000, lanes=64)
+        k, model, pred, resid, _ = oracle.select_best(ped, p0, fits["best"])
+        wraw, _ = oracle.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, w, 0, iters, lanes=8)
+        assert np.array_equal(raw[:, :, w], wraw)
+        f = lines[1 + w].split(";")
+        assert f[0] == "t" and int(f[1]) == w and f[3] == ["upstream", "upstream", "gene", "gene", "downstream"][w]
+        assert float(f[4]) == model[0] and float(f[5]) == model[1]
+        assert float(f[8]) == 1.0 - p0
+        an = oracle.analyze(wraw)
+        assert float(f[9]) == an[1, 0] and float(f[10]) == an[1, 1]
