@@ -135,7 +135,8 @@ static int upload_topology(abn_ctx* c, const Topology& t, DevTopology& d) {
 // launch configuration
 // ------------------------------------------------------------------------------------------------
 constexpr size_t kMaxDynLds = 64 * 1024;
-constexpr size_t kLdsResidentMax = 40 * 1024;  // above this the fit kernel streams rows instead of staging them
+constexpr size_t kLdsResidentMax = 40 * 1024;
+constexpr int kPhaseACap = 1000;  // first-pass iteration cap of the two-pass phase A  // above this the fit kernel streams rows instead of staging them
 
 // Lanes of a wavefront per chain.  Auto: by pedigree rows, then widened until the workgroup's LDS
 // (64/G chains x chain_stride doubles) leaves room for >= 8 workgroups per CU (160 KiB LDS).
@@ -159,16 +160,21 @@ static int pick_rmax(int n, int lanes) {
   return 0;  // stream mode
 }
 
-template <int G>
-static hipError_t launch_fit_g(const FitArgs& a, int rmax, dim3 grid, size_t lds, hipStream_t s) {
+template <int G, bool TP>
+static hipError_t launch_fit_gt(const FitArgs& a, int rmax, dim3 grid, size_t lds, hipStream_t s) {
   switch (rmax) {
-    case 1: hipLaunchKernelGGL((abn_fit_kernel<G, 1>), grid, dim3(kWave), lds, s, a); break;
-    case 2: hipLaunchKernelGGL((abn_fit_kernel<G, 2>), grid, dim3(kWave), lds, s, a); break;
-    case 4: hipLaunchKernelGGL((abn_fit_kernel<G, 4>), grid, dim3(kWave), lds, s, a); break;
-    case 8: hipLaunchKernelGGL((abn_fit_kernel<G, 8>), grid, dim3(kWave), lds, s, a); break;
-    default: hipLaunchKernelGGL((abn_fit_kernel<G, 0>), grid, dim3(kWave), lds, s, a); break;
+    case 1: hipLaunchKernelGGL((abn_fit_kernel<G, 1, TP>), grid, dim3(kWave), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((abn_fit_kernel<G, 2, TP>), grid, dim3(kWave), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((abn_fit_kernel<G, 4, TP>), grid, dim3(kWave), lds, s, a); break;
+    case 8: hipLaunchKernelGGL((abn_fit_kernel<G, 8, TP>), grid, dim3(kWave), lds, s, a); break;
+    default: hipLaunchKernelGGL((abn_fit_kernel<G, 0, TP>), grid, dim3(kWave), lds, s, a); break;
   }
   return hipGetLastError();
+}
+template <int G>
+static hipError_t launch_fit_g(const FitArgs& a, int rmax, dim3 grid, size_t lds, hipStream_t s) {
+  const bool twopass = a.iter_cap > 0 || a.resume != 0;
+  return twopass ? launch_fit_gt<G, true>(a, rmax, grid, lds, s) : launch_fit_gt<G, false>(a, rmax, grid, lds, s);
 }
 
 // `a.chain_stride` must be the topology's scratch stride (9*TP + KP + 4); the resident variant adds N doubles.
@@ -579,6 +585,9 @@ struct abn_plan {
   DevBuf<int32_t> best_start;
   DevBuf<uint32_t> idx;
   DevBuf<double> dstar;  // stream mode: materialised bootstrap observations [W x B x N]
+  DevBuf<double> nm_state;    // two-pass phase A: parked Nelder-Mead states [W x S x 32]
+  DevBuf<int> susp_list;      // [W x S] + 1 counter at the end
+  bool twopass_a = false;
   bool stream_b = false;
   double* raw = nullptr;  // raw_own.p or caller-bound
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -658,6 +667,14 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   PALLOC(bestB, W * B * 4);
   PALLOC(infoB, W * B);
   PALLOC(raw_own, W * B * 7);
+  // Phase A with many chains: 7 % of random starts never reach SD < EPSILON and run all 10000 iterations; in
+  // one launch such a chain may be dispatched late and then runs alone for tens of milliseconds.  Two passes:
+  // every chain for at most kPhaseACap iterations, then the unfinished ones, compacted, all resident at once.
+  p->twopass_a = (long long)n_windows * n_starts > 4096 && p->opt.max_iters_start > kPhaseACap;
+  if (p->twopass_a) {
+    PALLOC(nm_state, W * S * 32);
+    PALLOC(susp_list, W * S + 1);
+  }
   p->stream_b = n_boot > 0 && fit_streams(n_rows, p->topo.chain_stride, p->lanes) && p->opt.stream_mode == 0;
   if (p->stream_b) PALLOC(dstar, W * B * N);
 #undef PALLOC
@@ -767,7 +784,26 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once
   const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && (long long)wn * p->S <= 2048 &&
                     spec_applicable(a);
-  int rc = spec ? launch_fit_spec(c, a, st) : launch_fit(c, a, spec ? 64 : p->lanes_a, st);
+  int rc;
+  if (spec) {
+    rc = launch_fit_spec(c, a, st);
+  } else if (p->twopass_a && w0 == 0 && wn == p->W) {
+    int* cnt = p->susp_list.p + (size_t)p->W * S;
+    HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(int), st));
+    a.state = p->nm_state.p;
+    a.susp_list = p->susp_list.p;
+    a.susp_count = cnt;
+    a.iter_cap = kPhaseACap;
+    a.resume = 0;
+    rc = launch_fit(c, a, p->lanes_a, st);          // pass 1: everybody, capped
+    if (!rc) {
+      a.iter_cap = 0;
+      a.resume = 1;
+      rc = launch_fit(c, a, p->lanes_a, st);        // pass 2: the parked chains, to the end
+    }
+  } else {
+    rc = launch_fit(c, a, p->lanes_a, st);
+  }
   if (rc) return rc;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[1], st));
   SelectArgs s{};
@@ -1018,7 +1054,7 @@ extern "C" int abn_plan_device_bytes(abn_plan* p, int64_t* bytes) {
   t += p->D.bytes() + p->pred.bytes() + p->resid.bytes() + p->p_uu.bytes() + p->eqp.bytes() + p->eqp_w.bytes();
   t += p->simplexA.bytes() + p->bestA.bytes() + p->model.bytes() + p->lse.bytes() + p->bestB.bytes();
   t += p->raw_own.bytes() + p->infoA.bytes() + p->infoB.bytes() + p->best_start.bytes() + p->idx.bytes();
-  t += p->dstar.bytes();
+  t += p->dstar.bytes() + p->nm_state.bytes() + p->susp_list.bytes();
   t += p->dtopo.tri.bytes() + p->dtopo.tid.bytes();
   *bytes = (int64_t)t;
   return ABN_OK;

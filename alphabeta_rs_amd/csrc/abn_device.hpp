@@ -38,6 +38,7 @@ constexpr int ST_EXPAND = 6;    // evaluating the expanded point
 constexpr int ST_CONTRACT = 7;  // evaluating the contracted point
 constexpr int ST_SHRINK1 = 8;   // 8..11: evaluating shrunk vertex k = st-7
 constexpr int ST_DONE = 12;
+constexpr int kFitSuspended = 4;  // internal status between the two passes of a long chain
 
 struct FitInfoDev {  // layout of abn_fit_info (include/abneutral.h)
   double best_cost;
@@ -74,6 +75,16 @@ struct FitArgs {
   // chains: W windows x C chains
   int W, C;
   int max_iters;
+  // Two-pass execution of long chains (abn_api.hip: phase A with many chains).  Pass 1: iter_cap > 0 — a chain
+  // that is still running after iter_cap iterations stores its Nelder-Mead state (32 doubles) and appends its
+  // index to susp_list.  Pass 2: resume != 0 — block b, group g continues chain susp_list[b*NG+g] (for
+  // b*NG+g < *susp_count) from the stored state to the end.  Same arithmetic either way: results are
+  // bit-identical to an uninterrupted run.
+  int iter_cap;          // 0 = unlimited
+  int resume;
+  double* state;         // [W*C*32]
+  int* susp_list;        // [W*C]
+  int* susp_count;       // [1]
   int shrink_variant;
   double sd_tol;
   double gap_tol;        // 64 * sd_tol, precomputed on the host so that it stays a scalar (kernarg) operand
@@ -352,7 +363,7 @@ __device__ __forceinline__ double group_sum_dpp(double v) {
 // index row is re-streamed from HBM, coalesced).
 // LDS per workgroup: 64/G chains x (9(T+1) + KP + 4 [+ NP]) doubles.
 // ------------------------------------------------------------------------------------------------
-template <int G, int RMAX>
+template <int G, int RMAX, bool TWOPASS = false>
 __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
   constexpr int NG = kWave / G;
   constexpr bool STREAM = (RMAX == 0);
@@ -364,8 +375,15 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
   const int gl = lane - g * G;
   const int dim = gl & 3;
   const long long total = (long long)a.W * a.C;
-  const long long chain_raw = (long long)blockIdx.x * NG + g;
-  const bool valid = chain_raw < total;
+  const long long slot = (long long)blockIdx.x * NG + g;
+  long long chain_raw = slot;
+  bool valid = slot < total;
+  if constexpr (TWOPASS) {
+    if (a.resume) {  // second pass: the compacted list of suspended chains
+      valid = slot < (long long)*a.susp_count;
+      chain_raw = valid ? (long long)a.susp_list[slot] : 0;
+    }
+  }
   const long long chain = valid ? chain_raw : 0;
   const int w = (int)(chain / a.C);
   const int j = (int)(chain - (long long)w * a.C);
@@ -593,8 +611,9 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
     else if (best_cost <= -__builtin_inf()) status = 3;
     // results are written after the loop (keeps output addresses out of the loop's registers); plain
     // selects here: conditional stores to two different scalars made hipcc spill them to scratch
-    const bool done = status >= 0;
-    fin_status = done ? (have_best ? status : 2) : fin_status;
+    const bool suspend = TWOPASS && status < 0 && a.iter_cap > 0 && iter >= a.iter_cap;  // first of two passes
+    const bool done = status >= 0 || suspend;
+    fin_status = (status >= 0) ? (have_best ? status : 2) : (suspend ? kFitSuspended : fin_status);
     // centroid (p0 + p1 + p2 + p3) * (1/4), reflection x0 + (x0 - worst) * alpha
     double acc = vx[0];
     acc = acc + vx[1];
@@ -606,24 +625,49 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
     st = done ? ST_DONE : ST_REFLECT;
   };
 
-  // Solver::init: the five start costs in input order, stable sort, first termination check.  All chains
-  // of a wavefront start together.
+  if (!TWOPASS || !a.resume) {
+    // Solver::init: the five start costs in input order, stable sort, first termination check.  All chains
+    // of a wavefront start together.
 #pragma unroll 1
-  for (int k = 0; k < 5; ++k) {
-    const double f = eval(vx[0]);
-    const double tv = vx[0];
+    for (int k = 0; k < 5; ++k) {
+      const double f = eval(vx[0]);
+      const double tv = vx[0];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      c[q] = c[q + 1];
-      vx[q] = vx[q + 1];
+      for (int q = 0; q < 4; ++q) {
+        c[q] = c[q + 1];
+        vx[q] = vx[q + 1];
+      }
+      c[4] = f;
+      vx[4] = tv;
     }
-    c[4] = f;
-    vx[4] = tv;
-  }
-  if (valid) {
-    evals = 5;
-    sort5(c, vx);
-    begin_iteration(false);
+    if (valid) {
+      evals = 5;
+      sort5(c, vx);
+      begin_iteration(false);
+    }
+  } else if (TWOPASS && valid) {
+    // continue a suspended chain: simplex (this lane's dimension), costs, best-so-far and counters as stored
+    // at an iteration boundary; centroid and reflection are recomputed (same arithmetic, same bits)
+    const double* sp = a.state + (size_t)chain * 32;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      vx[k] = sp[4 * k + dim];
+      c[k] = sp[20 + k];
+    }
+    bx = sp[25 + dim];
+    best_cost = sp[29];
+    const int* ip = reinterpret_cast<const int*>(sp + 30);
+    iter = ip[0];
+    evals = ip[1];
+    have_best = ip[2] != 0;
+    double acc = vx[0];
+    acc = acc + vx[1];
+    acc = acc + vx[2];
+    acc = acc + vx[3];
+    x0 = acc * (1.0 / 4.0);
+    xr = x0 + (x0 - vx[4]) * 1.0;
+    xc = xr;
+    st = ST_REFLECT;
   }
 
   while (__ballot(st != ST_DONE) != 0ull) {
@@ -686,6 +730,26 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
     a.dbg[7] = (unsigned long long)evals;
   }
 #endif
+  // ---- first pass of a two-pass run: park the chains that hit the iteration cap
+  if (TWOPASS && valid && fin_status == kFitSuspended) {
+    double* sp = a.state + (size_t)chain * 32;
+    if (gl < 4) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) sp[4 * k + gl] = vx[k];
+      sp[25 + gl] = bx;
+    }
+    if (gl == 0) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) sp[20 + k] = c[k];
+      sp[29] = best_cost;
+      int* ip = reinterpret_cast<int*>(sp + 30);
+      ip[0] = iter;
+      ip[1] = evals;
+      ip[2] = have_best ? 1 : 0;
+      ip[3] = 0;
+      a.susp_list[atomicAdd(a.susp_count, 1)] = (int)chain;
+    }
+  }
   // ---- results in fit order: best_param, (best_cost, iters, evals, status, lanes) and, for bootstraps,
   // the row [alpha, beta, weight, intercept, est_mm, est_um, est_uu] of src/boot_model.rs:86-91
   const double b0 = dpp_mov<kDppQuadBcast0>(bx), b1 = dpp_mov<kDppQuadBcast1>(bx);

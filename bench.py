@@ -49,6 +49,12 @@ def make_workload(name: str, rank: int, world: int):
         return dict(gens=gens, D=D, p0=p0, S=10, B=1000, wr=25,
                     label="C4 shard: C3 topology, 25 windows x (10 starts + 1000 bootstraps) per GPU "
                           "(200 windows over 8 GPUs)")
+    if name == "mp":
+        # the reference's default metaprofile shape (src/cli/metaprofile.rs:40-44 with -s 1: 3 regions x 100
+        # windows; --iterations 100 -> 100 starts + 100 bootstraps per window), on the C3 topology
+        gens, D, p0, _ = synthetic.c4_windows(300, window_offset=300 * rank)
+        return dict(gens=gens, D=D, p0=p0, S=100, B=100, wr=300,
+                    label="metaprofile shape: C3 topology, 300 windows x (100 starts + 100 bootstraps) per GPU")
     if name == "c5s":
         ped, p = synthetic.c5_pedigree()
         rng = np.random.Generator(np.random.Philox(key=synthetic.SEED + 500 + rank))
@@ -137,7 +143,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "g351", "c5s"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "g351", "c5s", "mp"])
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stream-probe", action="store_true",

@@ -540,3 +540,33 @@ def test_metaprofile_batch_driver(abn, gpu_ctx, golden, oracle, tmp_path):
         assert float(f[8]) == 1.0 - p0
         an = oracle.analyze(wraw)
         assert float(f[9]) == an[1, 0] and float(f[10]) == an[1, 1]
+
+
+def test_two_pass_phase_a_is_bit_identical(abn, gpu_ctx, golden, oracle):
+    """Phase A with more than 4096 start chains runs in two passes (every chain for at most 1000 iterations,
+    then the parked ones from their stored Nelder-Mead state): iterations, evaluations and fitted vectors
+    must equal an uninterrupted run.  Many starts on the bundled pedigree run all 10000 iterations."""
+    ped, p0 = golden["generated"], golden["p0uu_generated"]
+    W, S, seed = 52, 80, 77
+    rng = np.random.default_rng(2)
+    D = np.abs(ped[:, 3][None, :] * rng.uniform(0.7, 1.3, (W, 1)))
+    p0w = rng.uniform(0.6, 0.8, W)
+    o = abn.default_options(seed=seed)
+    plan = abn.Plan(gpu_ctx, ped[:, :3], W, S, 2, options=o)
+    plan.set_windows(D, p0w)
+    plan.run()
+    out = plan.download()
+    plan.close()
+    it = out["info_a"]["iters"]
+    assert (it > 1000).sum() > 50 and (it == 10000).sum() > 10      # the cap was exercised
+    assert np.all(out["info_a"]["status"] != 4)                       # nothing left parked
+    la = int(out["info_a"]["lanes"][0, 0])
+    for w in (0, 17, 51):
+        pw = np.concatenate([ped[:, :3], D[w][:, None]], axis=1)
+        s0 = abn.gen_start_simplices(seed, w, S, D[w].max())
+        fits = oracle.fit_batch(pw, p0w[w], p0w[w], 1.0, s0, 10000, lanes=la)
+        assert np.array_equal(out["info_a"]["iters"][w], fits["iters"])
+        assert np.array_equal(out["info_a"]["evals"][w], fits["evals"])
+        assert np.array_equal(out["info_a"]["status"][w], fits["status"])
+        k, model, _, _, _ = oracle.select_best(pw, p0w[w], fits["best"])
+        assert out["best_start"][w] == k and np.array_equal(out["models"][w], model)
