@@ -183,7 +183,7 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
   if (chains <= 0) return ABN_OK;
   const int ng = kWave / lanes;
   int rmax = pick_rmax(a.N, lanes);
-  const int np = (a.N + 1) & ~1;
+  const int np = ((a.N + 1) & ~1) + ((a.K + 1) / 2);  // resident observations + this chain's triple list
   if (rmax > 0) {
     if ((size_t)ng * (size_t)(a.chain_stride + np) * sizeof(double) > kLdsResidentMax) rmax = 0;
     else a.chain_stride += np;
@@ -208,7 +208,7 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
 // true when launch_fit will use the stream variant for this pedigree / lane count
 static bool fit_streams(int n, int chain_stride, int lanes) {
   if (pick_rmax(n, lanes) == 0) return true;
-  const int np = (n + 1) & ~1;
+  const int np = ((n + 1) & ~1) + n / 2 + 1;  // observations + triple list (K <= n)
   return (size_t)(kWave / lanes) * (size_t)(chain_stride + np) * sizeof(double) > kLdsResidentMax;
 }
 

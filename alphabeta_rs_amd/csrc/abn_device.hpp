@@ -364,7 +364,7 @@ __device__ __forceinline__ double group_sum_dpp(double v) {
 // LDS per workgroup: 64/G chains x (9(T+1) + KP + 4 [+ NP]) doubles.
 // ------------------------------------------------------------------------------------------------
 template <int G, int RMAX, bool TWOPASS = false>
-__global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
+__global__ __launch_bounds__(kWave, TWOPASS ? 2 : 3) void abn_fit_kernel(const FitArgs a) {
   constexpr int NG = kWave / G;
   constexpr bool STREAM = (RMAX == 0);
   constexpr int RR = RMAX > 0 ? RMAX : 1;
@@ -409,14 +409,15 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
   }
   // ---- resident mode: observed divergences staged in LDS once per fit (bootstrap: gathered through the
   // index row); this lane's triples and row->triple ids (as LDS byte offsets into dt) in registers
-  uint32_t triv[RR], tidp[(RR + 1) / 2];  // tidp: two 16-bit triple ids per register
+  uint32_t tidp[(RR + 1) / 2];  // two 16-bit triple ids per register
+  uint32_t* tri_s = reinterpret_cast<uint32_t*>(dobs + ((N + 1) & ~1));  // this chain's copy of the triple list
   if (!STREAM) {
+    for (int t = gl; t < K; t += G) tri_s[t] = a.tri[t];
 #pragma unroll
     for (int q = 0; q < (RR + 1) / 2; ++q) tidp[q] = 0u;
 #pragma unroll
     for (int q = 0; q < RR; ++q) {
       const int i = gl + G * q;
-      triv[q] = (i < K) ? a.tri[i] : 0u;
       if (i < N) {
         tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
         dobs[i] = (a.dmode == 1) ? a.pred[wN + i] + a.resid[wN + idx_row[i]]  // src/boot_model.rs:50-54
@@ -466,13 +467,9 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
     build_power_table<G>(Gm, a.T, TP, pw, gl);               // P2
     __syncthreads();
     ABN_STAMP(1);
-    if (!STREAM) {                                           // P3
-#pragma unroll
-      for (int q = 0; q < RR; ++q) {
-        const int t = gl + G * q;
-        if (t < K) dtab[t] = triple_dt(triv[q], pw, TP, sv0, sv1, sv2);
-        __builtin_amdgcn_sched_barrier(0);  // one triple at a time (register pressure)
-      }
+    if (!STREAM) {                                           // P3: ceil(K/G) rounds, one triple per lane
+#pragma unroll 1
+      for (int t = gl; t < K; t += G) dtab[t] = triple_dt(tri_s[t], pw, TP, sv0, sv1, sv2);
     } else {
       for (int t = gl; t < K; t += G) dtab[t] = triple_dt(a.tri[t], pw, TP, sv0, sv1, sv2);
     }
@@ -482,17 +479,16 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_kernel(const FitArgs a) {
     if (!STREAM) {
       double dv[RR], tv[RR];
 #pragma unroll
-      for (int q = 0; q < RR; ++q) {                         // all LDS reads first, then the arithmetic
-        const bool in = (gl + G * q) < N;
-        dv[q] = in ? dobs[gl + G * q] : 0.0;
-        tv[q] = in ? dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu] : 0.0;
+      for (int q = 0; q < RR; ++q) {                         // all LDS reads first, then the arithmetic;
+        const int i = gl + G * q;                            // rows past the end read row N-1 and add +0.0
+        dv[q] = dobs[i < N ? i : N - 1];
+        tv[q] = dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu];
       }
 #pragma unroll
       for (int q = 0; q < RR; ++q) {
-        if ((gl + G * q) < N) {
-          const double r = dv[q] - ic - tv[q];
-          acc = acc + (r * r + pen);
-        }
+        const double r = dv[q] - ic - tv[q];
+        const double term = r * r + pen;
+        acc = acc + (((gl + G * q) < N) ? term : 0.0);       // x + 0.0 == x bit for bit (acc is never -0.0)
       }
     } else {
       // stream mode.  Lane l owns row blocks of kStreamVec = 4 consecutive rows: rows 4(l + G q) .. +3 for
