@@ -54,6 +54,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
 HOST = PKG / "host"
 CLI = PKG / "bin" / "alphabeta"
 META_CLI = PKG / "bin" / "metaprofile_alphabeta"
+REF_TESTS = PKG / "bin" / "reference_tests"
 PEDIGREE_LIB = PKG / "libabneutral_host.so"
 
 
@@ -62,7 +63,7 @@ def build_host(force: bool = False, verbose: bool = False) -> Path:
     library exposing Pedigree::build to the tests.  Both link libabneutral_hip.so via $ORIGIN rpaths."""
     build_hip()
     srcs = [HOST / "alphabeta_cli.cpp", HOST / "alphabeta.hpp", HOST / "pedigree_build.hpp", HOST / "host_capi.cpp",
-            HOST / "metaprofile.hpp", HOST / "metaprofile_cli.cpp"]
+            HOST / "metaprofile.hpp", HOST / "metaprofile_cli.cpp", HOST / "reference_tests.cpp"]
     newest = max(p.stat().st_mtime for p in srcs)
     CLI.parent.mkdir(exist_ok=True)
     common = ["-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-I", str(PKG.parent / "include")]
@@ -74,6 +75,12 @@ def build_host(force: bool = False, verbose: bool = False) -> Path:
         subprocess.run(cmd, check=True, cwd=str(PKG))
     if force or not META_CLI.exists() or META_CLI.stat().st_mtime < newest:
         cmd = [hipcc_path(), *common, "-o", str(META_CLI), str(HOST / "metaprofile_cli.cpp"), "-L", str(PKG),
+               "-labneutral_hip", "-Wl,-rpath,$ORIGIN/.."]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=str(PKG))
+    if force or not REF_TESTS.exists() or REF_TESTS.stat().st_mtime < newest:
+        cmd = [hipcc_path(), *common, "-o", str(REF_TESTS), str(HOST / "reference_tests.cpp"), "-L", str(PKG),
                "-labneutral_hip", "-Wl,-rpath,$ORIGIN/.."]
         if verbose:
             print(" ".join(cmd))

@@ -261,6 +261,28 @@ struct Problem {  // src/structs.rs:11-19
   }
 };
 
+namespace divergence {
+struct Divergence {  // src/divergence.rs:10-14
+  std::vector<double> dt1t2;
+  double p_uu;
+};
+// src/divergence.rs:33-94 (one candidate through abn_cost_batch; `_p_um` is unused there as well)
+inline Divergence divergence(const Pedigree& pedigree, double p_mm, double /*_p_um*/, double p_uu, double alpha,
+                             double beta, double weight) {
+  Device& dev = default_device();
+  if (p_mm != 1.0 - p_uu)  // the device path derives p_mm as the callers do (src/ab_neutral.rs:23)
+    throw Error(ABN_ERR_INVALID_ARG, "divergence: p_mm must equal 1 - p_uu");
+  const double x[4] = {alpha, beta, weight, 0.0};
+  Divergence d;
+  d.dt1t2.resize(pedigree.nrows());
+  double c = 0.0;
+  dev.check(abn_cost_batch(dev.get(), &dev.options, pedigree.data.data(), (int32_t)pedigree.nrows(), p_uu, p_uu, 0.0, x,
+                           1, nullptr, nullptr, nullptr, nullptr, 0, &c, d.dt1t2.data(), &d.p_uu),
+            "divergence");
+  return d;
+}
+}  // namespace divergence
+
 namespace ab_neutral {
 // src/ab_neutral.rs:13-20
 inline std::tuple<Model, PredictedDivergence, Residuals> run(const Pedigree& pedigree, double p0uu, double eqp,

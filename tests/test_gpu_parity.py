@@ -570,3 +570,27 @@ def test_two_pass_phase_a_is_bit_identical(abn, gpu_ctx, golden, oracle):
         assert np.array_equal(out["info_a"]["status"][w], fits["status"])
         k, model, _, _, _ = oracle.select_best(pw, p0w[w], fits["best"])
         assert out["best_start"][w] == k and np.array_equal(out["models"][w], model)
+
+
+def test_reference_unit_tests_through_the_cpp_mirror(abn, gpu_ctx):
+    """The reference's enabled unit tests on the path (same_as_r, test_cost_function, build_pedigree) restated
+    against the C++ mirror of its API and executed on the GPU (alphabeta_rs_amd/host/reference_tests.cpp).
+    The fixtures sit where the reference expects them relative to the working directory: ./data/..."""
+    import shutil
+    import subprocess
+    import tempfile
+    from pathlib import Path
+
+    from alphabeta_rs_amd import build as B
+
+    B.build_host()
+    gold = Path(__file__).resolve().parent / "golden"
+    with tempfile.TemporaryDirectory() as td:
+        shutil.copytree(gold / "data", Path(td) / "data")
+        shutil.copy(gold / "pedigree.txt", Path(td) / "data" / "pedigree.txt")
+        shutil.copy(gold / "divergence.txt", Path(td) / "data" / "divergence.txt")
+        shutil.copy(gold / "pedigree_generated.txt", Path(td) / "pedigree_generated.txt")
+        r = subprocess.run([str(B.REF_TESTS)], capture_output=True, text=True, cwd=td)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "same_as_r ... ok" in r.stdout and "test_cost_function ... ok" in r.stdout
+    assert "build_pedigree ... ok" in r.stdout
