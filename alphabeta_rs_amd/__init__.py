@@ -186,12 +186,19 @@ def analyze(raw) -> np.ndarray:
 
 
 class Context:
-    """abn_ctx: one HIP device + stream.  `stream` may be a raw hipStream_t (int) to borrow."""
+    """abn_ctx: one HIP device + stream.  `stream`: None = a private stream owned by the context; 0 = the
+    device's default (null) stream (torch's current stream unless switched); otherwise a raw hipStream_t."""
 
     def __init__(self, device: int = 0, stream: int | None = None):
         self._L = load_library()
         h = C.c_void_p()
-        rc = self._L.abn_init(device, C.c_void_p(stream) if stream else None, C.byref(h))
+        if stream is None:
+            sp = None
+        elif stream == 0:
+            sp = C.c_void_p(-1)  # ABN_STREAM_DEFAULT
+        else:
+            sp = C.c_void_p(stream)
+        rc = self._L.abn_init(device, sp, C.byref(h))
         if rc:
             raise AbnError(rc, "abn_init failed (no HIP device? the ABneutral path has no CPU fallback)")
         self._h = h

@@ -285,7 +285,10 @@ extern "C" int abn_init(int device_ordinal, void* stream, abn_ctx** out) {
   abn_ctx* c = new (std::nothrow) abn_ctx();
   if (!c) return ABN_ERR_HIP;
   c->device = device_ordinal;
-  if (stream) {
+  if (stream == ABN_STREAM_DEFAULT) {
+    c->stream = nullptr;  // the null stream
+    c->own_stream = false;
+  } else if (stream) {
     c->stream = (hipStream_t)stream;
     c->own_stream = false;
   } else {

@@ -191,7 +191,7 @@ def main():
 
     def step():
         plan.run()                               # phase A -> select -> phase B on torch's current stream
-        if world > 1:
+        if world > 1:                            # (same stream: the collective is ordered after the kernels)
             dist.all_gather_into_tensor(raw_all.view(-1), raw_local.view(-1))
 
     def fence():
@@ -220,6 +220,15 @@ def main():
     cnt = plan.counters()
     out = plan.download()
     if world > 1:
+        # the gathered table must hold every rank's shard: compare per-rank checksums
+        step()
+        fence()
+        mine = raw_local.sum().reshape(1)
+        sums = torch.empty(world, dtype=torch.float64, device="cuda")
+        dist.all_gather_into_tensor(sums, mine)
+        got = raw_all.view(world, -1).sum(dim=1)
+        if not torch.equal(got, sums):
+            raise SystemExit(f"rank {rank}: gathered bootstrap table does not match the shards")
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())

@@ -75,8 +75,10 @@ typedef struct abn_fit_info {
 /* ------------------------------------------------------------------ context */
 void abn_default_options(abn_options* opts);
 int abn_device_count(int* count);
-/* stream == NULL: the context creates (and owns) its own non-blocking HIP stream; otherwise the given
- * hipStream_t is borrowed (e.g. torch.cuda.current_stream().cuda_stream). */
+/* stream == NULL: the context creates (and owns) its own non-blocking HIP stream; ABN_STREAM_DEFAULT: the
+ * device's default (null) stream — what torch.cuda.current_stream() is unless the caller switched streams;
+ * otherwise the given hipStream_t is borrowed (e.g. torch.cuda.current_stream().cuda_stream != 0). */
+#define ABN_STREAM_DEFAULT ((void*)(intptr_t)-1)
 int abn_init(int device_ordinal, void* stream, abn_ctx** ctx);
 int abn_shutdown(abn_ctx* ctx);
 const char* abn_last_error(const abn_ctx* ctx);
