@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Randomised plan-level parity sweep (development aid): phase A (speculative / two-pass / plain), selection,
+phase B (resident / stream) against per-window oracle runs."""
+import sys, time
+from pathlib import Path
+import numpy as np
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import alphabeta_rs_amd as A
+import oracle as O
+from fuzz_parity import rand_ped
+
+def main(seconds=180, seed=0):
+    ctx = A.Context(0)
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + seconds
+    cases = fails = 0
+    while time.time() < t_end:
+        n = int(rng.choice([3, 6, 40, 105, 200, 600]))
+        tmax = int(rng.choice([1, 4, 8, 16]))
+        ped = rand_ped(rng, n, tmax)
+        W = int(rng.choice([1, 2, 5, 60]))
+        S = int(rng.choice([1, 3, 10, 90])) if W < 60 else 90       # 60 x 90 > 4096 -> two-pass phase A
+        B = int(rng.choice([1, 4, 16]))
+        mi_a, mi_b = int(rng.choice([1500, 3000])), int(rng.choice([100, 400]))
+        variant = int(rng.integers(0, 2))
+        seed_o = int(rng.integers(1, 1 << 30))
+        D = np.abs(ped[:, 3][None, :] * rng.uniform(0.7, 1.3, (W, 1)) + rng.normal(0, 1e-4, (W, n)))
+        p0 = rng.uniform(0.55, 0.95, W)
+        woff, boff = int(rng.integers(0, 1000)), int(rng.integers(0, 5000))
+        o = A.default_options(seed=seed_o, shrink_on_failed_contraction=variant, max_iters_start=mi_a, max_iters_boot=mi_b,
+                              stream_mode=int(rng.integers(0, 2)))
+        plan = A.Plan(ctx, ped[:, :3], W, S, B, window_offset=woff, boot_offset=boff, options=o)
+        plan.set_windows(D, p0)
+        plan.run()
+        out = plan.download()
+        plan.close()
+        la, lb = int(out["info_a"]["lanes"][0, 0]), int(out["info_b"]["lanes"][0, 0])
+        ok = True
+        for w in sorted(set([0, W - 1, int(rng.integers(0, W))])):
+            pw = np.concatenate([ped[:, :3], D[w][:, None]], axis=1)
+            s0 = A.gen_start_simplices(seed_o, woff + w, S, D[w].max())
+            fits = O.fit_batch(pw, p0[w], p0[w], 1.0, s0, mi_a, shrink_variant=variant, lanes=la)
+            ok = ok and np.array_equal(out["info_a"]["iters"][w], fits["iters"]) and np.array_equal(out["info_a"]["evals"][w], fits["evals"])
+            k, model, pred, resid, _ = O.select_best(pw, p0[w], fits["best"])
+            ok = ok and out["best_start"][w] == k
+            if k >= 0:
+                ok = ok and np.array_equal(out["models"][w], model)
+                wraw, wres = O.boot_model(pw, model, pred, resid, p0[w], p0[w], 1.0, seed_o, woff + w, boff, B, max_iters=mi_b,
+                                          shrink_variant=variant, lanes=lb)
+                ok = ok and np.array_equal(out["raw"][w], wraw, equal_nan=True) and np.array_equal(out["info_b"]["evals"][w], wres["evals"])
+        cases += 1
+        if not ok:
+            fails += 1
+            print("MISMATCH", dict(n=n, tmax=tmax, W=W, S=S, B=B, variant=variant, la=la, lb=lb, mi_a=mi_a), flush=True)
+    print(f"fuzz_plan: {cases} cases, {fails} mismatches")
+    return fails
+
+if __name__ == "__main__":
+    sys.exit(1 if main(int(sys.argv[1]) if len(sys.argv) > 1 else 180, int(sys.argv[2]) if len(sys.argv) > 2 else 0) else 0)
