@@ -4,7 +4,7 @@ phase B (resident / stream) against per-window oracle runs."""
 import sys, time
 from pathlib import Path
 import numpy as np
-sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 import alphabeta_rs_amd as A
 import oracle as O
 from fuzz_parity import rand_ped
