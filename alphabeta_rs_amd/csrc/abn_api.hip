@@ -901,8 +901,8 @@ extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
 // Whole pass.  opts.window_groups > 1 cuts the plan into contiguous window groups that run A -> select -> B
 // on their own HIP streams (a window's bootstraps need only that window's starts), forking from and joining
 // back into the context's stream with events; results do not depend on the grouping and timing events are
-// recorded for group 0.  Measured on MI355X / ROCm 7.2 (scripts/groups_bench.py, C4 shard): the groups'
-// kernels did not overlap (23 ms with 1 group, 43 ms with 8), so the default is ONE group.
+// recorded for group 0.  Streams share a few in-order hardware queues (4 by default), so more than 4 groups
+// serialise behind each other; see scripts/groups_bench.py for the measured effect.
 extern "C" int abn_plan_run(abn_plan* p) {
   if (!p) return ABN_ERR_INVALID_ARG;
   abn_ctx* c = p->ctx;
@@ -937,8 +937,11 @@ extern "C" int abn_plan_run(abn_plan* p) {
     if (!rc) rc = enqueue_phase_b(p, w0, w1 - w0, st, g == 0);
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(p->ev_join[(size_t)g], st));
-    HIPCHK(c, hipStreamWaitEvent(c->stream, p->ev_join[(size_t)g], 0));
   }
+  // Join only after every group has been enqueued: HIP multiplexes streams onto a few in-order hardware
+  // queues, and a wait packet of the main stream placed between the launches would hold back whichever side
+  // stream shares its queue (scripts/stream_overlap_test.hip: 10 ms instead of 5 ms for four 5 ms kernels).
+  for (int g = 0; g < groups; ++g) HIPCHK(c, hipStreamWaitEvent(c->stream, p->ev_join[(size_t)g], 0));
   p->phase_a_done = true;
   p->ran_a = true;
   p->ran_b = true;

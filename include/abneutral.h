@@ -60,7 +60,9 @@ typedef struct abn_options {
   double sd_tolerance;                  /* f64::EPSILON (argmin default, never overridden)             */
   int32_t window_groups;                /* abn_plan_run: windows are cut into this many groups that run
                                            A -> select -> B concurrently on separate HIP streams
-                                           (0 or 1 = one stream, the default: no gain measured)                    */
+                                           (0 or 1 = one stream, the default; at most 4 overlap: HIP maps
+                                           streams onto 4 in-order hardware queues.  Measured gain on a
+                                           25-window shard: 2 %, the slowest start chain sets the time)                    */
   int32_t reserved1;
 } abn_options;
 

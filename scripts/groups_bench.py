@@ -8,7 +8,7 @@ import alphabeta_rs_amd as A
 from alphabeta_rs_amd import synthetic
 ctx = A.Context(0)
 gens, D, p0, _ = synthetic.c4_windows(25)
-for g in (1, 2, 4, 8, 25):
+for g in (1, 2, 3, 4, 8):
     plan = A.Plan(ctx, gens, 25, 10, 1000, options=A.default_options(window_groups=g))
     plan.set_windows(D, p0)
     plan.run(); plan.sync()
