@@ -57,7 +57,7 @@ class Options(C.Structure):
         ("stream_mode", C.c_int32),
         ("sd_tolerance", C.c_double),
         ("window_groups", C.c_int32),
-        ("reserved1", C.c_int32),
+        ("no_fixed_point_skip", C.c_int32),
     ]
 
 
@@ -395,9 +395,10 @@ class Plan:
                 "best_start": bs}
 
     def counters(self):
-        out = (C.c_int64 * 3)()
+        out = (C.c_int64 * 5)()
         self.ctx._check(self._L.abn_plan_counters(self._h, out))
-        return {"fits": out[0], "evals": out[1], "iters": out[2]}
+        return {"fits": out[0], "evals": out[1], "iters": out[2], "evals_skipped": out[3] + out[4],
+                "evals_skipped_starts": out[3], "evals_skipped_boot": out[4]}
 
     def device_bytes(self) -> int:
         b = C.c_int64()

@@ -252,7 +252,7 @@ extern "C" void abn_default_options(abn_options* o) {
   o->stream_mode = 0;
   o->sd_tolerance = 2.220446049250313e-16;  // f64::EPSILON
   o->window_groups = 0;
-  o->reserved1 = 0;
+  o->no_fixed_point_skip = 0;
 }
 
 static abn_options resolve(const abn_options* o) {
@@ -556,6 +556,8 @@ extern "C" int abn_fit_batch(abn_ctx* c, const abn_options* opts, const double* 
   }
   a.max_iters = max_iters;
   a.shrink_variant = o.shrink_on_failed_contraction ? 1 : 0;
+  a.no_skip = o.no_fixed_point_skip ? 1 : 0;
+  a.skipped = nullptr;
   a.sd_tol = o.sd_tolerance;
   a.gap_tol = 64.0 * o.sd_tolerance;
   a.best = dbest.p;
@@ -590,6 +592,7 @@ struct abn_plan {
   DevBuf<double> dstar;  // stream mode: materialised bootstrap observations [W x B x N]
   DevBuf<double> nm_state;    // two-pass phase A: parked Nelder-Mead states [W x S x 32]
   DevBuf<int> susp_list;      // [W x S] + 1 counter at the end
+  DevBuf<unsigned long long> skipped;  // [2] evaluations not executed (fixed-point skip) in phase A, phase B
   bool twopass_a = false;
   bool stream_b = false;
   double* raw = nullptr;  // raw_own.p or caller-bound
@@ -670,6 +673,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   PALLOC(bestB, W * B * 4);
   PALLOC(infoB, W * B);
   PALLOC(raw_own, W * B * 7);
+  PALLOC(skipped, 2);
   // Phase A with many chains: 7 % of random starts never reach SD < EPSILON and run all 10000 iterations; in
   // one launch such a chain may be dispatched late and then runs alone for tens of milliseconds.  Two passes:
   // every chain for at most kPhaseACap iterations, then the unfinished ones, compacted, all resident at once.
@@ -758,6 +762,7 @@ static void fill_common(const abn_plan* p, FitArgs& a) {
   a.boot_offset = p->boot_offset;
   a.W = p->W;
   a.shrink_variant = p->opt.shrink_on_failed_contraction ? 1 : 0;
+  a.no_skip = p->opt.no_fixed_point_skip ? 1 : 0;
   a.sd_tol = p->opt.sd_tolerance;
   a.gap_tol = 64.0 * p->opt.sd_tolerance;
 }
@@ -783,6 +788,7 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   a.best = p->bestA.p + o * S * 4;
   a.info = p->infoA.p + o * S;
   a.raw = nullptr;
+  a.skipped = p->skipped.p;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[0], st));
   // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once
   const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && (long long)wn * p->S <= 2048 &&
@@ -857,6 +863,7 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   a.best = p->bestB.p + o * B * 4;
   a.info = p->infoB.p + o * B;
   a.raw = p->raw + o * B * 7;
+  a.skipped = p->skipped.p + 1;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[4], st));
   if (p->stream_b) {  // gather the bootstrap observations once per fit, then stream them
     double* dst = p->dstar.p + o * B * N;
@@ -881,6 +888,7 @@ extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
   HIPCHK(c, hipSetDevice(c->device));
   if (phase == 0) {
     if (p->S <= 0) return set_err(c, ABN_ERR_STATE, "plan has no starts");
+    HIPCHK(c, hipMemsetAsync(p->skipped.p, 0, sizeof(unsigned long long), c->stream));
     int rc = enqueue_phase_a(p, 0, p->W, c->stream, true);
     if (rc) return rc;
     p->phase_a_done = true;
@@ -890,6 +898,7 @@ extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
   if (phase == 1) {
     if (p->B <= 0) return set_err(c, ABN_ERR_STATE, "plan has no bootstraps");
     if (!p->phase_a_done) return set_err(c, ABN_ERR_STATE, "phase A has not run");
+    HIPCHK(c, hipMemsetAsync(p->skipped.p + 1, 0, sizeof(unsigned long long), c->stream));
     int rc = enqueue_phase_b(p, 0, p->W, c->stream, true);
     if (rc) return rc;
     p->ran_b = true;
@@ -928,6 +937,7 @@ extern "C" int abn_plan_run(abn_plan* p) {
     HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     p->ev_join.push_back(e);
   }
+  HIPCHK(c, hipMemsetAsync(p->skipped.p, 0, 2 * sizeof(unsigned long long), c->stream));
   HIPCHK(c, hipEventRecord(p->ev_fork, c->stream));
   for (int g = 0; g < groups; ++g) {
     const int w0 = (int)((long long)p->W * g / groups), w1 = (int)((long long)p->W * (g + 1) / groups);
@@ -1004,33 +1014,37 @@ extern "C" int abn_plan_download(abn_plan* p, double* models, double* pred, doub
   return ABN_OK;
 }
 
-extern "C" int abn_plan_counters(abn_plan* p, int64_t* out3) {
-  if (!p || !out3) return ABN_ERR_INVALID_ARG;
+extern "C" int abn_plan_counters(abn_plan* p, int64_t* out5) {
+  int64_t* out4 = out5;
+  if (!p || !out5) return ABN_ERR_INVALID_ARG;
   abn_ctx* c = p->ctx;
-  out3[0] = out3[1] = out3[2] = 0;
+  out4[0] = out4[1] = out4[2] = out4[3] = out4[4] = 0;
   std::vector<FitInfoDev> h;
-  auto add = [&](const DevBuf<FitInfoDev>& b) -> int {
+  auto add = [&](const DevBuf<FitInfoDev>& b, int phase) -> int {
     if (!b.n) return ABN_OK;
     h.resize(b.n);
+    unsigned long long sk = 0;
     HIPCHK(c, hipMemcpyAsync(h.data(), b.p, b.bytes(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&sk, p->skipped.p + phase, sizeof sk, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (const auto& f : h) {
-      out3[0] += 1;
-      out3[1] += f.evals;
-      out3[2] += f.iters;
+      out4[0] += 1;
+      out4[1] += f.evals;
+      out4[2] += f.iters;
     }
+    out4[3 + phase] = (int64_t)sk;
     return ABN_OK;
   };
   int rc = ABN_OK;
-  if (p->ran_a) rc = add(p->infoA);
+  if (p->ran_a) rc = add(p->infoA, 0);
   if (rc) return rc;
-  if (p->ran_b) rc = add(p->infoB);
+  if (p->ran_b) rc = add(p->infoB, 1);
   return rc;
 }
 
 #ifdef ABN_STAMPS
 // diagnostic build only: run phase A with in-kernel stamps, return the 8 cycle sums of chain 0
-extern "C" int abn_plan_debug_stamps(abn_plan* p, unsigned long long* out8) {
+static int debug_stamps(abn_plan* p, unsigned long long* out8, bool spec) {
   abn_ctx* c = p->ctx;
   DevBuf<unsigned long long> d;
   HIPCHK(c, d.alloc(8));
@@ -1046,12 +1060,15 @@ extern "C" int abn_plan_debug_stamps(abn_plan* p, unsigned long long* out8) {
   a.info = p->infoA.p;
   a.raw = nullptr;
   a.dbg = d.p;
-  int rc = launch_fit(c, a, p->lanes, c->stream);
+  int rc = spec ? launch_fit_spec(c, a, c->stream) : launch_fit(c, a, p->lanes, c->stream);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(out8, d.p, 64, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return ABN_OK;
 }
+extern "C" int abn_plan_debug_stamps(abn_plan* p, unsigned long long* out8) { return debug_stamps(p, out8, false); }
+// the same for the speculative three-wavefront kernel (wavefront 0 of chain 0; out8[7] = iterations)
+extern "C" int abn_plan_debug_stamps_spec(abn_plan* p, unsigned long long* out8) { return debug_stamps(p, out8, true); }
 #endif
 
 extern "C" int abn_plan_device_bytes(abn_plan* p, int64_t* bytes) {
@@ -1060,7 +1077,7 @@ extern "C" int abn_plan_device_bytes(abn_plan* p, int64_t* bytes) {
   t += p->D.bytes() + p->pred.bytes() + p->resid.bytes() + p->p_uu.bytes() + p->eqp.bytes() + p->eqp_w.bytes();
   t += p->simplexA.bytes() + p->bestA.bytes() + p->model.bytes() + p->lse.bytes() + p->bestB.bytes();
   t += p->raw_own.bytes() + p->infoA.bytes() + p->infoB.bytes() + p->best_start.bytes() + p->idx.bytes();
-  t += p->dstar.bytes() + p->nm_state.bytes() + p->susp_list.bytes();
+  t += p->dstar.bytes() + p->nm_state.bytes() + p->susp_list.bytes() + p->skipped.bytes();
   t += p->dtopo.tri.bytes() + p->dtopo.tid.bytes();
   *bytes = (int64_t)t;
   return ABN_OK;

@@ -25,6 +25,14 @@ namespace abn {
 
 constexpr int kWave = 64;
 constexpr int kStreamVec = 4;  // consecutive rows per lane and block in stream mode
+#ifndef ABN_STREAM_BLOCKS
+#define ABN_STREAM_BLOCKS 6
+#endif
+#ifndef ABN_STREAM_WAVES
+#define ABN_STREAM_WAVES 2
+#endif
+constexpr int kStreamWaves = ABN_STREAM_WAVES;    // wavefronts per SIMD the stream variant is compiled for
+constexpr int kStreamBlocks = ABN_STREAM_BLOCKS;  // row blocks a lane keeps in flight per loop iteration
 
 // element-aligned vector types: global loads on gfx950 need dword alignment only
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -86,6 +94,13 @@ struct FitArgs {
   int* susp_list;        // [W*C]
   int* susp_count;       // [1]
   int shrink_variant;
+  // argmin 0.8.1 leaves the simplex untouched after a rejected contraction (shrink_variant == 0), and the cost
+  // function is deterministic: from then on every iteration repeats the same two evaluations and the same
+  // rejection until max_iters.  no_skip == 0: such a chain is finished on the spot with the counters it would
+  // have reached (iters = max_iters, evals += 2 per remaining iteration, status MAX_ITERS) — the same outputs
+  // as running the repetitions.  The evaluations not executed are summed into *skipped (nullable).
+  int no_skip;
+  unsigned long long* skipped;
   double sd_tol;
   double gap_tol;        // 64 * sd_tol, precomputed on the host so that it stays a scalar (kernarg) operand
   // outputs (fit order)
@@ -364,7 +379,7 @@ __device__ __forceinline__ double group_sum_dpp(double v) {
 // LDS per workgroup: 64/G chains x (9(T+1) + KP + 4 [+ NP]) doubles.
 // ------------------------------------------------------------------------------------------------
 template <int G, int RMAX, bool TWOPASS = false>
-__global__ __launch_bounds__(kWave, TWOPASS ? 2 : 3) void abn_fit_kernel(const FitArgs a) {
+__global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)) void abn_fit_kernel(const FitArgs a) {
   constexpr int NG = kWave / G;
   constexpr bool STREAM = (RMAX == 0);
   constexpr int RR = RMAX > 0 ? RMAX : 1;
@@ -497,51 +512,57 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : 3) void abn_fit_kernel(const F
       // in flight per iteration, the dependent residual gathers issued together.  The per-lane accumulation
       // order (block by block, row by row) is what the oracle's lanes code `G | 3 << 8` reproduces.
       constexpr int V = kStreamVec;
+      constexpr int NB = kStreamBlocks;                              // full blocks in flight per lane
       const int stride = V * G;
       int base = V * gl;
-      for (; base + stride + V <= N; base += 2 * stride) {          // two full blocks
-        double d[2 * V], t[2 * V];
-        const u16x4 tq0 = *reinterpret_cast<const u16x4*>(a.tid + base);
-        const u16x4 tq1 = *reinterpret_cast<const u16x4*>(a.tid + base + stride);
+      for (; base + (NB - 1) * stride + V <= N; base += NB * stride) {
+        double d[NB * V], t[NB * V];
+        u16x4 tq[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) tq[b] = *reinterpret_cast<const u16x4*>(a.tid + base + b * stride);
         if (a.dmode == 1) {
-          const u32x4 ix0 = *reinterpret_cast<const u32x4*>(idx_row + base);
-          const u32x4 ix1 = *reinterpret_cast<const u32x4*>(idx_row + base + stride);
-          const f64x2 p00 = *reinterpret_cast<const f64x2*>(a.pred + wN + base);
-          const f64x2 p01 = *reinterpret_cast<const f64x2*>(a.pred + wN + base + 2);
-          const f64x2 p10 = *reinterpret_cast<const f64x2*>(a.pred + wN + base + stride);
-          const f64x2 p11 = *reinterpret_cast<const f64x2*>(a.pred + wN + base + stride + 2);
+          u32x4 ix[NB];
+          f64x2 pl[NB], ph[NB];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            ix[b] = *reinterpret_cast<const u32x4*>(idx_row + base + b * stride);
+            pl[b] = *reinterpret_cast<const f64x2*>(a.pred + wN + base + b * stride);
+            ph[b] = *reinterpret_cast<const f64x2*>(a.pred + wN + base + b * stride + 2);
+          }
           const double* rs = a.resid + wN;
-          const double r0 = rs[ix0[0]], r1 = rs[ix0[1]], r2 = rs[ix0[2]], r3 = rs[ix0[3]];
-          const double r4 = rs[ix1[0]], r5 = rs[ix1[1]], r6 = rs[ix1[2]], r7 = rs[ix1[3]];
-          d[0] = p00[0] + r0;  // src/boot_model.rs:50-54
-          d[1] = p00[1] + r1;
-          d[2] = p01[0] + r2;
-          d[3] = p01[1] + r3;
-          d[4] = p10[0] + r4;
-          d[5] = p10[1] + r5;
-          d[6] = p11[0] + r6;
-          d[7] = p11[1] + r7;
+          double rg[NB * V];
+#pragma unroll
+          for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int e = 0; e < V; ++e) rg[b * V + e] = rs[ix[b][e]];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {                             // src/boot_model.rs:50-54
+            d[b * V + 0] = pl[b][0] + rg[b * V + 0];
+            d[b * V + 1] = pl[b][1] + rg[b * V + 1];
+            d[b * V + 2] = ph[b][0] + rg[b * V + 2];
+            d[b * V + 3] = ph[b][1] + rg[b * V + 3];
+          }
         } else {
-          const f64x2 q00 = *reinterpret_cast<const f64x2*>(a.D + dN + base);
-          const f64x2 q01 = *reinterpret_cast<const f64x2*>(a.D + dN + base + 2);
-          const f64x2 q10 = *reinterpret_cast<const f64x2*>(a.D + dN + base + stride);
-          const f64x2 q11 = *reinterpret_cast<const f64x2*>(a.D + dN + base + stride + 2);
-          d[0] = q00[0];
-          d[1] = q00[1];
-          d[2] = q01[0];
-          d[3] = q01[1];
-          d[4] = q10[0];
-          d[5] = q10[1];
-          d[6] = q11[0];
-          d[7] = q11[1];
+          f64x2 ql[NB], qh[NB];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            ql[b] = *reinterpret_cast<const f64x2*>(a.D + dN + base + b * stride);
+            qh[b] = *reinterpret_cast<const f64x2*>(a.D + dN + base + b * stride + 2);
+          }
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            d[b * V + 0] = ql[b][0];
+            d[b * V + 1] = ql[b][1];
+            d[b * V + 2] = qh[b][0];
+            d[b * V + 3] = qh[b][1];
+          }
         }
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-          t[e] = dtab[tq0[e]];
-          t[V + e] = dtab[tq1[e]];
-        }
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-        for (int e = 0; e < 2 * V; ++e) {
+          for (int e = 0; e < V; ++e) t[b * V + e] = dtab[tq[b][e]];
+#pragma unroll
+        for (int e = 0; e < NB * V; ++e) {
           const double r = d[e] - ic - t[e];
           acc = acc + (r * r + pen);
         }
@@ -682,6 +703,12 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : 3) void abn_fit_kernel(const F
     const bool start_shrink = nan_ref || (rej_c && a.shrink_variant != 0);
     const bool do_begin = do_insert || (rej_c && a.shrink_variant == 0);  // argmin 0.8.1: rejected contraction leaves the simplex
     evals += active ? 1 : 0;
+    if (rej_c && a.shrink_variant == 0 && a.no_skip == 0) {  // fixed point: finish the chain (FitArgs::no_skip)
+      const int rest = a.max_iters - iter - 1;               // iterations that would repeat this one
+      evals += 2 * rest;
+      iter += rest;
+      if (a.skipped && gl == 0 && rest > 0) atomicAdd(a.skipped, 2ull * (unsigned long long)rest);
+    }
     const double xi = keep_r ? xr : xc;
     const double fi = keep_r ? fr : f;
     fr = is_ref ? f : fr;
@@ -835,7 +862,12 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
     for (int k = 0; k < 5; ++k) vx[k] = s0[4 * k + dim];
   }
 
+#ifdef ABN_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
   auto eval = [&](double xd) -> double {
+    ABN_STAMP(6);  // Nelder-Mead bookkeeping + candidate since the exchange
     const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
     const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
     const Gen Gm = genmatrix(al, be);
@@ -844,8 +876,10 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
     const double puu = p_uu_est(al, be);
     const double dq = puu - wconst[2];
     const double pen = wconst[3] * (dq * dq);
+    ABN_STAMP(0);
     build_power_table<G>(Gm, a.T, TP, pw, gl);
     wave_lds_fence();
+    ABN_STAMP(1);
 #pragma unroll
     for (int q = 0; q < RMAX; ++q) {
       const int t = gl + G * q;
@@ -853,6 +887,7 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
       __builtin_amdgcn_sched_barrier(0);
     }
     wave_lds_fence();
+    ABN_STAMP(2);
     double acc = 0.0;
     double dv[RMAX], tv[RMAX];
 #pragma unroll
@@ -870,6 +905,7 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
     }
     acc = group_sum_dpp<G>(acc);
     wave_lds_fence();
+    ABN_STAMP(3);
     return acc;
   };
 
@@ -883,6 +919,7 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
     f1 = buf[1];
     f2 = buf[2];
     phase ^= 1;  // the other buffer next time: no second barrier needed
+    ABN_STAMP(4);
   };
 
   int st = ST_REFLECT;
@@ -960,6 +997,7 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
       begin_iteration(false);
       mode = (st == ST_DONE) ? M_DONE : M_ITER;
     } else if (mode == M_ITER) {
+      // wave-uniform branches (measured: faster than the predicated form of abn_fit_kernel for a lone chain)
       const double fr = f0, fe = f1, fc = f2;
       if (fr < c[3] && fr >= c[0]) {          // reflection accepted
         evals += 1;
@@ -983,8 +1021,14 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
           sorted_begin = true;
         } else if (a.shrink_variant) {
           start_shrink = true;
-        } else {
-          sorted_begin = true;                // argmin 0.8.1: rejected contraction leaves the simplex
+        } else {                              // argmin 0.8.1: rejected contraction leaves the simplex
+          if (a.no_skip == 0) {               // ... for good: finish the chain (FitArgs::no_skip)
+            const int rest = a.max_iters - iter - 1;
+            evals += 2 * rest;
+            iter += rest;
+            if (a.skipped && wv == 0 && gl == 0 && rest > 0) atomicAdd(a.skipped, 2ull * (unsigned long long)rest);
+          }
+          sorted_begin = true;
         }
       } else {                                // NaN reflection cost
         evals += 1;
@@ -1013,6 +1057,12 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
     }
   }
 
+#ifdef ABN_STAMPS
+  if (a.dbg && chain == 0 && wv == 0 && gl == 0) {
+    for (int q = 0; q < 8; ++q) a.dbg[q] = seg[q];
+    a.dbg[7] = (unsigned long long)iter;
+  }
+#endif
   const double b0 = dpp_mov<kDppQuadBcast0>(bx), b1 = dpp_mov<kDppQuadBcast1>(bx);
   if (wv == 0) {
     if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;

@@ -61,8 +61,8 @@ def make_workload(name: str, rank: int, world: int):
         D = np.maximum(ped[:, 3] + (rng.normal(0.0, synthetic.NOISE_SD, ped.shape[0]) if world > 1 else 0.0), 0.0)
         return dict(gens=ped[:, :3], D=D[None, :], p0=np.array([p]), S=4, B=4096, wr=1,
                     label="C5 shard: synthetic deep pedigree, 8 lineages x 125 generations (N=20100 rows, T=125, "
-                          "K=950), 4 starts + 4096 bootstraps, 1 window per GPU; rows streamed (u32 index row "
-                          "re-read from HBM every evaluation)")
+                          "K=950), 4 starts + 4096 bootstraps, 1 window per GPU; rows streamed (the materialised "
+                          "bootstrap observations, 8 B/row, re-read from HBM every evaluation)")
     if name in ("c2", "g351"):
         # fixtures are data (tests/golden); read without the oracle package
         fn = "pedigree_generated.txt" if name == "c2" else "pedigree.txt"
@@ -77,44 +77,79 @@ def make_workload(name: str, rank: int, world: int):
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(wl, model, pred, resid, lanes, seed, budget_s=12.0):
+def usable_cpus(limit):
+    """Host threads this process may really run at once: the affinity mask and the cgroup CPU quota, whichever
+    is smaller (a GPU box hands one GPU's share of the host's cores to the job)."""
+    n = min(limit, len(os.sched_getaffinity(0)))
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = Path(path).read_text().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def cpu_baseline(wl, model, pred, resid, lanes, seed, evals_per_fit, budget_s=12.0):
     """The CPU oracle (a port of the reference's algorithm: per-row repeated 3x3 multiplication,
-    src/divergence.rs:51-90, one OpenMP thread per fit like the rayon par_iter) on a bounded sample."""
+    src/divergence.rs:51-90, one OpenMP thread per fit like the rayon par_iter) on a bounded sample.
+    A probe of one truncated fit per thread sizes the sample; pedigrees whose full fits do not fit the
+    budget are timed on truncated fits and converted with the measured evaluations per fit."""
     import oracle as O
 
     O.build()
     ped = np.concatenate([wl["gens"], wl["D"][0][:, None]], axis=1)
     p0 = float(wl["p0"][0])
-    cores = O.max_threads()
-    nb = 64 * cores
-    t0 = time.perf_counter()
-    _, res = O.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, nb, lanes=1, table=False)
-    dt = time.perf_counter() - t0
-    scale = max(1.0, min(16.0, budget_s / max(dt, 1e-3)))
-    nb2 = int(nb * scale)
-    t0 = time.perf_counter()
-    _, res = O.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, nb2, lanes=1, table=False)
-    dt = time.perf_counter() - t0
-    t1 = time.perf_counter()
-    _, res_t = O.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, nb2, lanes=1, table=True)
-    dt_t = time.perf_counter() - t1
+    cores = usable_cpus(O.max_threads())
+
+    def run(nb, iters, table):
+        t0 = time.perf_counter()
+        _, res = O.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, nb, max_iters=iters, lanes=1, table=table,
+                              threads=cores)
+        return time.perf_counter() - t0, float(res["evals"].sum())
+
+    nb, iters = cores, 4                                # probe: 5 + <= 8 evaluations per fit and thread
+    for _ in range(5):
+        dt, ev = run(nb, iters, False)
+        if dt >= budget_s / 3.0:
+            break
+        target = ev / dt * budget_s                     # evaluations the budget buys at the measured rate
+        if target >= 4.0 * cores * evals_per_fit:       # whole fits: >= 4 per thread
+            nb, iters = int(min(1024.0 * cores, target / evals_per_fit)), 1000
+        else:                                           # truncated fits, one per thread
+            nb, iters = cores, max(4, int(target / cores / 1.7) - 5)
+    dt_t, ev_t = run(nb, iters, True)
+    whole = iters == 1000
+    fits = nb / dt if whole else ev / dt / evals_per_fit
+    fits_t = nb / dt_t if whole else ev_t / dt_t / evals_per_fit
+    what = (f"{nb} residual-bootstrap refits of window 0" if whole else
+            f"{nb} residual-bootstrap refits of window 0 truncated at {iters} Nelder-Mead iterations ({int(ev)} "
+            f"evaluations; fits/s = evaluations/s / {evals_per_fit:.1f} evaluations per fit measured on the GPU run)")
     return {
-        "value": nb2 / dt, "unit": "fits/s", "cores": cores, "kind": "port",
-        "sample": f"{nb2} residual-bootstrap refits of window 0 (same pedigree, same inputs), reference-shaped "
-                  f"divergence (3 matrix_power per row), {cores} OpenMP threads, {dt:.1f} s",
-        "evals_per_s": float(res["evals"].sum()) / dt,
-        "power_table_variant_fits_per_s": nb2 / dt_t,
+        "value": fits, "unit": "fits/s", "cores": cores, "kind": "port",
+        "sample": f"{what} (same pedigree, same inputs), reference-shaped divergence (3 matrix_power per row), "
+                  f"{cores} OpenMP threads, {dt:.1f} s",
+        "evals_per_s": ev / dt,
+        "power_table_variant_fits_per_s": fits_t,
     }
 
 
 def stream_probe(A, ctx, seed, steps=2):
-    """Short run of the HBM-facing configuration (a C5 shard, stream mode: the u32 bootstrap index row is
-    re-read from HBM on every evaluation) so that the bench line also carries the roofline of the kernel
+    """Short run of the HBM-facing configuration (a C5 shard, stream mode: the bootstrap observations of a fit
+    are re-read from HBM on every evaluation) so that the bench line also carries the roofline of the kernel
     variant the HBM roof actually applies to.  Phase B only is timed (HIP events on the launch stream)."""
     from alphabeta_rs_amd import synthetic
 
     ped, p = synthetic.c5_pedigree()
-    N, B = ped.shape[0], 2048
+    N, B = ped.shape[0], 8192
     plan = A.Plan(ctx, ped[:, :3], 1, 2, B, options=A.default_options(seed=seed))
     plan.set_windows(ped[:, 3][None, :], np.array([p]))
     plan.run()
@@ -124,7 +159,7 @@ def stream_probe(A, ctx, seed, steps=2):
         ms += plan.kernel_ms()["fit_boot"]
     ms /= steps
     out = plan.download()
-    evals_b = int(out["info_b"]["evals"].sum())
+    evals_b = int(out["info_b"]["evals"].sum()) - plan.counters()["evals_skipped_boot"]  # evaluations executed
     lanes = int(out["info_b"]["lanes"][0, 0])
     plan.close()
     alg = evals_b * (4 * N + 40) + B * 112 + N * 18
@@ -232,16 +267,21 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([cnt["fits"], cnt["evals"], cnt["iters"]], dtype=torch.int64, device="cuda")
+        # evaluations EXECUTED: fits that reach argmin's fixed point are finished without repeating it
+        # (options.no_fixed_point_skip); those evaluations are in info.evals but were not computed
+        c = torch.tensor([cnt["fits"], cnt["evals"] - cnt["evals_skipped"], cnt["iters"], cnt["evals_skipped"]],
+                         dtype=torch.int64, device="cuda")
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        tot_fits, tot_evals, tot_iters = (int(v) for v in c.tolist())
+        tot_fits, tot_evals, tot_iters, tot_skipped = (int(v) for v in c.tolist())
         if by_boot:  # the replicated phase-A fits are counted once
             ia = out["info_a"]
             tot_fits -= (world - 1) * ia.size
-            tot_evals -= (world - 1) * int(ia["evals"].sum())
+            tot_evals -= (world - 1) * (int(ia["evals"].sum()) - cnt["evals_skipped_starts"])
             tot_iters -= (world - 1) * int(ia["iters"].sum())
+            tot_skipped -= (world - 1) * cnt["evals_skipped_starts"]
     else:
-        tot_fits, tot_evals, tot_iters = cnt["fits"], cnt["evals"], cnt["iters"]
+        tot_fits, tot_evals, tot_iters = cnt["fits"], cnt["evals"] - cnt["evals_skipped"], cnt["iters"]
+        tot_skipped = cnt["evals_skipped"]
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -251,7 +291,7 @@ def main():
         K = len({tuple(r) for r in wl["gens"].astype(int).tolist()})
         T = int(wl["gens"].max())
         # ---- roofline of the dominant kernel (phase-B fit kernel), per launch on this rank
-        fits_b, evals_b = Wr * B, int(out["info_b"]["evals"].sum())
+        fits_b, evals_b = Wr * B, int(out["info_b"]["evals"].sum()) - cnt["evals_skipped_boot"]
         stream = (lanes >> 8) != 0        # row-block code set: the pedigree is streamed every evaluation
         lanes &= 0xff
         if stream:
@@ -301,6 +341,7 @@ def main():
                                                                  "one RCCL all-gather of the bootstrap tables"},
             "candidate_evals_per_s": evals_per_s,
             "fits_per_step": tot_fits, "evals_per_step": tot_evals, "nm_iters_per_step": tot_iters,
+            "evals_not_executed_per_step": tot_skipped,
             "kernel_ms": kms,
             "roofline": roofline,
         }
@@ -309,7 +350,8 @@ def main():
         if not args.no_cpu_baseline:
             bs = int(out["best_start"][0])
             if bs >= 0:
-                result["cpu_baseline"] = cpu_baseline(wl, out["models"][0], out["pred"][0], out["resid"][0], lanes, seed)
+                result["cpu_baseline"] = cpu_baseline(wl, out["models"][0], out["pred"][0], out["resid"][0], lanes, seed,
+                                                      float(out["info_b"]["evals"][0].mean()))
         print(json.dumps(result))
     plan.close()
     ctx.close()

@@ -63,7 +63,12 @@ typedef struct abn_options {
                                            (0 or 1 = one stream, the default; at most 4 overlap: HIP maps
                                            streams onto 4 in-order hardware queues.  Measured gain on a
                                            25-window shard: 2 %, the slowest start chain sets the time)                    */
-  int32_t reserved1;
+  int32_t no_fixed_point_skip;          /* 0 (default): a fit whose contraction is rejected has reached a fixed
+                                           point of argmin 0.8.1's iteration (the simplex is left untouched and
+                                           the cost is deterministic), so it is finished at once with the counters
+                                           the repetitions would have produced (iters = max_iters, evals += 2 per
+                                           remaining iteration, ABN_FIT_MAX_ITERS): identical outputs.  1 = execute
+                                           the repetitions like the reference does                             */
 } abn_options;
 
 typedef struct abn_fit_info {
@@ -192,8 +197,10 @@ int abn_plan_bind_raw(abn_plan* plan, void* dev_ptr);
  * raw[W x B x 7], info_a[W x S], info_b[W x B], best_start[W] (int32, -1 = ABN_ERR_NO_FINITE_FIT) */
 int abn_plan_download(abn_plan* plan, double* models, double* pred, double* resid, double* raw,
                       abn_fit_info* info_a, abn_fit_info* info_b, int32_t* best_start);
-/* sums over all fits of the last run (for evals/s): out[0] = fits, out[1] = evals, out[2] = iters */
-int abn_plan_counters(abn_plan* plan, int64_t* out3);
+/* sums over all fits of the last run (for evals/s): out[0] = fits, out[1] = evals (cost() calls of the reference
+ * algorithm = sum of abn_fit_info.evals), out[2] = iters, out[3] / out[4] = evaluations of out[1] in the start / bootstrap
+ * fits that were NOT executed because the fit had reached a fixed point (options.no_fixed_point_skip) */
+int abn_plan_counters(abn_plan* plan, int64_t* out5);
 /* number of bytes of device memory the plan holds (index buffer included) */
 int abn_plan_device_bytes(abn_plan* plan, int64_t* bytes);
 

@@ -34,3 +34,22 @@ for lanes in (16, 64):
             print(f"  {names[q]:26s} {out[q] / ev:8.1f} cyc/eval  {100.0 * out[q] / tot:5.1f}%")
     print(f"  total {tot / ev:.1f} cyc/eval (stamps add ~40 each)")
     plan.close()
+
+# speculative three-wavefront kernel (phase A): wavefront 0 of chain 0, per ITERATION
+L.abn_plan_debug_stamps_spec.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+names = ["P1 bcast+genmatrix+puu", "P2 power table", "P3 triples", "P4+P5 rows, reduce", "exchange (LDS + barrier)", "-",
+         "P6 NM update + candidates", "iters"]
+plan = A.Plan(ctx, ped[:, :3], 1, 1, 0, options=A.default_options())
+plan.set_windows(ped[:, 3][None, :], np.array([p0]))
+out = (C.c_uint64 * 8)()
+for _ in range(3):
+    rc = L.abn_plan_debug_stamps_spec(plan._h, out)
+assert rc == 0
+it = out[7]
+tot = sum(out[q] for q in range(7))
+print(f"spec kernel iters={it}")
+for q in range(7):
+    if names[q] != "-":
+        print(f"  {names[q]:26s} {out[q] / it:8.1f} cyc/iter  {100.0 * out[q] / tot:5.1f}%")
+print(f"  total {tot / it:.1f} cyc/iter (stamps add ~40 each)")
+plan.close()

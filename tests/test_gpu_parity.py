@@ -542,23 +542,27 @@ def test_metaprofile_batch_driver(abn, gpu_ctx, golden, oracle, tmp_path):
         assert float(f[9]) == an[1, 0] and float(f[10]) == an[1, 1]
 
 
-def test_two_pass_phase_a_is_bit_identical(abn, gpu_ctx, golden, oracle):
+@pytest.mark.parametrize("no_skip", (1, 0))
+def test_two_pass_phase_a_is_bit_identical(abn, gpu_ctx, golden, oracle, no_skip):
     """Phase A with more than 4096 start chains runs in two passes (every chain for at most 1000 iterations,
     then the parked ones from their stored Nelder-Mead state): iterations, evaluations and fitted vectors
-    must equal an uninterrupted run.  Many starts on the bundled pedigree run all 10000 iterations."""
+    must equal an uninterrupted run.  Many starts on the bundled pedigree run all 10000 iterations
+    (no_skip = 1: the repetitions of a stuck fit are executed, so those chains go through the parking)."""
     ped, p0 = golden["generated"], golden["p0uu_generated"]
     W, S, seed = 52, 80, 77
     rng = np.random.default_rng(2)
     D = np.abs(ped[:, 3][None, :] * rng.uniform(0.7, 1.3, (W, 1)))
     p0w = rng.uniform(0.6, 0.8, W)
-    o = abn.default_options(seed=seed)
+    o = abn.default_options(seed=seed, no_fixed_point_skip=no_skip)
     plan = abn.Plan(gpu_ctx, ped[:, :3], W, S, 2, options=o)
     plan.set_windows(D, p0w)
     plan.run()
     out = plan.download()
+    cnt = plan.counters()
     plan.close()
     it = out["info_a"]["iters"]
     assert (it > 1000).sum() > 50 and (it == 10000).sum() > 10      # the cap was exercised
+    assert (cnt["evals_skipped"] == 0) == (no_skip == 1)
     assert np.all(out["info_a"]["status"] != 4)                       # nothing left parked
     la = int(out["info_a"]["lanes"][0, 0])
     for w in (0, 17, 51):
@@ -570,6 +574,52 @@ def test_two_pass_phase_a_is_bit_identical(abn, gpu_ctx, golden, oracle):
         assert np.array_equal(out["info_a"]["status"][w], fits["status"])
         k, model, _, _, _ = oracle.select_best(pw, p0w[w], fits["best"])
         assert out["best_start"][w] == k and np.array_equal(out["models"][w], model)
+
+
+def test_fixed_point_skip_changes_no_output(abn, gpu_ctx, golden, oracle):
+    """argmin 0.8.1 leaves the simplex untouched after a rejected contraction, so such a fit repeats the same
+    two evaluations until max_iters.  By default the kernels finish it on the spot with the counters the
+    repetitions would have produced; every output must equal the run that executes them (and the oracle,
+    which always executes them).  Covers the speculative phase-A kernel, the resident and the stream kernel."""
+    ped, p0 = golden["generated"], golden["p0uu_generated"]
+    W, S, B, seed = 12, 40, 64, 5
+    rng = np.random.default_rng(11)
+    D = np.abs(ped[:, 3][None, :] * rng.uniform(0.7, 1.3, (W, 1)))
+    p0w = rng.uniform(0.6, 0.8, W)
+    outs, cnts = [], []
+    for no_skip in (0, 1):
+        plan = abn.Plan(gpu_ctx, ped[:, :3], W, S, B, options=abn.default_options(seed=seed, no_fixed_point_skip=no_skip))
+        plan.set_windows(D, p0w)
+        plan.run()
+        outs.append(plan.download())
+        cnts.append(plan.counters())
+        plan.close()
+    for k in ("models", "pred", "resid", "raw", "best_start"):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+    for k in ("info_a", "info_b"):
+        assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
+    assert cnts[0]["evals"] == cnts[1]["evals"] and cnts[1]["evals_skipped"] == 0
+    assert cnts[0]["evals_skipped_starts"] > 0
+    stuck = outs[0]["info_a"]["iters"] == 10000
+    assert stuck.sum() > 5
+    # against the oracle (which executes the repetitions)
+    la = int(outs[0]["info_a"]["lanes"][0, 0])
+    w = int(np.argmax(stuck.sum(axis=1)))
+    pw = np.concatenate([ped[:, :3], D[w][:, None]], axis=1)
+    fits = oracle.fit_batch(pw, p0w[w], p0w[w], 1.0, abn.gen_start_simplices(seed, w, S, D[w].max()), 10000, lanes=la)
+    for k in ("status", "iters", "evals", "best_cost"):
+        assert np.array_equal(outs[0]["info_a"][w][k], fits[k], equal_nan=True), k
+    # plain (several chains per wavefront) and stream kernels through abn_fit_batch
+    big = synthetic_pedigree(np.random.default_rng(3), 700, 12)
+    for pedx, lanes, iters in ((ped, 16, 3000), (big, 64, 400)):
+        s0 = abn.gen_start_simplices(seed, 3, 24, pedx[:, 3].max())
+        res = [gpu_ctx.fit_batch(pedx, 0.7, 0.7, 1.0, s0, iters,
+                                 options=abn.default_options(lanes_per_chain=lanes, no_fixed_point_skip=ns))
+               for ns in (0, 1)]
+        assert np.array_equal(res[0][0], res[1][0], equal_nan=True)
+        assert res[0][1].tobytes() == res[1][1].tobytes()
+        want = oracle.fit_batch(pedx, 0.7, 0.7, 1.0, s0, iters, lanes=int(res[0][1]["lanes"][0]))
+        _assert_fits_equal(res[0][0], res[0][1], want)
 
 
 def test_reference_unit_tests_through_the_cpp_mirror(abn, gpu_ctx):
