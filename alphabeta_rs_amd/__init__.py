@@ -10,6 +10,7 @@ Python-level names mirror the reference crate: `Pedigree`, `Model`, `ab_neutral.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
@@ -18,6 +19,8 @@ from . import build as _build
 
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "libabneutral_hip.so"
+if os.environ.get("ABNEUTRAL_HIP_LIB"):  # development aid (scripts/flag_variants.py): another build of the same library
+    LIB_PATH = Path(os.environ["ABNEUTRAL_HIP_LIB"])
 
 ABN_OK = 0
 STATUS_NAMES = {

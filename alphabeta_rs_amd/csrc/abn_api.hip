@@ -212,13 +212,14 @@ static bool fit_streams(int n, int chain_stride, int lanes) {
   return (size_t)(kWave / lanes) * (size_t)(chain_stride + np) * sizeof(double) > kLdsResidentMax;
 }
 
-// Speculative three-wavefront kernel (phase A): resident mode with one wavefront per candidate only.
+// Speculative kernel (phase A; three evaluation wavefronts + a bookkeeping wavefront per chain): resident mode
+// with one wavefront per candidate only.
 static bool spec_applicable(const FitArgs& a) {
   if (a.dmode != 0 || a.smode != 0) return false;
   const int rmax = pick_rmax(a.N, kWave);
   if (rmax == 0) return false;
   const int np = (a.N + 1) & ~1;
-  return (3 * (size_t)(a.chain_stride + np) + 8) * sizeof(double) <= kLdsResidentMax;
+  return (3 * (size_t)(a.chain_stride + np) + kSpecCommDoubles) * sizeof(double) <= kLdsResidentMax;
 }
 
 static int launch_fit_spec(abn_ctx* c, FitArgs a, hipStream_t st) {
@@ -226,8 +227,8 @@ static int launch_fit_spec(abn_ctx* c, FitArgs a, hipStream_t st) {
   if (chains <= 0) return ABN_OK;
   const int rmax = pick_rmax(a.N, kWave);
   a.chain_stride += (a.N + 1) & ~1;
-  const size_t lds = (3 * (size_t)a.chain_stride + 8) * sizeof(double);
-  dim3 grid((unsigned)chains), block(3 * kWave);
+  const size_t lds = (3 * (size_t)a.chain_stride + kSpecCommDoubles) * sizeof(double);
+  dim3 grid((unsigned)chains), block(4 * kWave);
   switch (rmax) {
     case 1: hipLaunchKernelGGL(abn_fit_spec_kernel<1>, grid, block, lds, st, a); break;
     case 2: hipLaunchKernelGGL(abn_fit_spec_kernel<2>, grid, block, lds, st, a); break;
@@ -790,7 +791,8 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   a.raw = nullptr;
   a.skipped = p->skipped.p;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[0], st));
-  // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once
+  // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once,
+  // a fourth keeps the simplex and prepares the next candidates meanwhile (abn_fit_spec_kernel)
   const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && (long long)wn * p->S <= 2048 &&
                     spec_applicable(a);
   int rc;

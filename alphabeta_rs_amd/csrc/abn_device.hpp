@@ -802,12 +802,20 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
 // A Nelder-Mead iteration evaluates the reflection and then, depending on its cost, the expansion OR the
 // contraction point (argmin next_iter) — two dependent evaluations on ~70 % of the iterations.  All three
 // candidates are known before the first cost: x_r = x0 + (x0 - x_w), x_e = x0 + 2 (x_r - x0),
-// x_c = x0 + (x_w - x0)/2.  Here a chain owns a workgroup of THREE wavefronts (one per SIMD of a CU); each
-// evaluates one candidate with the G = 64 tree, the three costs are exchanged through LDS and every
-// wavefront takes the reference's decision on identical state.  Results, iteration and evaluation counts
-// (only evaluations the reference would have made are counted) are bit-identical to abn_fit_kernel<64,*>;
-// an iteration costs one evaluation latency instead of 1.7 on average.
-// Resident mode only (N <= 64*RMAX).  LDS: 3 x chain_stride doubles + 8 exchange doubles.
+// x_c = x0 + (x_w - x0)/2.  Here a chain owns a workgroup of FOUR wavefronts, one per SIMD of a CU:
+//   * wavefronts 0..2 evaluate one candidate each with the G = 64 tree and exchange the three costs through
+//     LDS.  Of the Nelder-Mead state they keep only what the control flow needs — the five sorted costs, the
+//     best cost and the iteration count — and take the reference's decision on them.
+//   * wavefront 3, the "keeper", owns the simplex (dimension per lane).  While the others evaluate the
+//     candidates of iteration i it works out, for every way iteration i can end — the accepted point is the
+//     reflection, expansion or contraction and lands at rank p of the new order: ten outcomes, one per quad
+//     of lanes — the three candidates of iteration i+1, and leaves them in LDS.  After the exchange an
+//     evaluation wavefront picks its next candidate from that table with one LDS read instead of doing the
+//     simplex update itself (which, on a lone wavefront, cost as much as 2/3 of an evaluation).
+// All four wavefronts derive the control flow from the same costs with the same code, so they reach the same
+// barriers.  Results, iteration and evaluation counts (only evaluations the reference would have made are
+// counted) are bit-identical to abn_fit_kernel<64,*>.
+// Resident mode only (N <= 64*RMAX).  LDS: 3 x chain_stride doubles + kSpecCommDoubles.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_lds_fence() {  // orders this wavefront's LDS writes before its reads
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -815,59 +823,63 @@ __device__ __forceinline__ void wave_lds_fence() {  // orders this wavefront's L
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+constexpr int kSpecOutcomes = 10;                                   // r@0..3, e@0, c@0..4
+constexpr int kSpecTabDoubles = kSpecOutcomes * 12;                 // [outcome][candidate r/e/c][dimension]
+constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16;      // cost exchange, two tables, shrink points
+
 template <int RMAX>
-__global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a) {
+__global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a) {
   constexpr int G = kWave;
   extern __shared__ __align__(16) double lds[];
-  const int wv = threadIdx.x >> 6;      // 0: reflection, 1: expansion, 2: contraction
+  const int wv = threadIdx.x >> 6;      // 0: reflection, 1: expansion, 2: contraction, 3: keeper
   const int gl = threadIdx.x & 63;
   const int dim = gl & 3;
+  const bool keeper = wv == 3;
   const long long chain = blockIdx.x;   // grid = W*C exactly
   const int w = (int)(chain / a.C);
   const int N = a.N, K = a.K, TP = a.TP;
 
-  double* pw = lds + (size_t)wv * a.chain_stride;
+  double* pw = lds + (size_t)(keeper ? 0 : wv) * a.chain_stride;  // the keeper never touches its alias
   double* dtab = pw + 9 * TP;
   double* wconst = dtab + ((K + 1) & ~1);
   double* dobs = wconst + 4;
   double* xch = lds + (size_t)3 * a.chain_stride;  // two buffers of 3 costs (+ pad)
+  double* tab = xch + 8;                           // two candidate tables
+  double* pts = tab + 2 * kSpecTabDoubles;         // NelderMead::shrink: the four moved vertices
 
   const int wi = w * a.wstride;
   const size_t wN = (size_t)w * (size_t)N;
-  if (gl == 0) {
-    const double p_uu0 = a.p_uu[wi];
-    wconst[0] = p_uu0;
-    wconst[1] = 1.0 - p_uu0;
-    wconst[2] = a.eqp[wi];
-    wconst[3] = a.eqp_w[wi] * (double)N;
-  }
   uint32_t triv[RMAX], tidp[(RMAX + 1) / 2];
 #pragma unroll
   for (int q = 0; q < (RMAX + 1) / 2; ++q) tidp[q] = 0u;
 #pragma unroll
-  for (int q = 0; q < RMAX; ++q) {
-    const int i = gl + G * q;
-    triv[q] = (i < K) ? a.tri[i] : 0u;
-    if (i < N) {
-      tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
-      dobs[i] = a.D[wN + i];  // phase-A observations (dmode 0); bootstraps use abn_fit_kernel
+  for (int q = 0; q < RMAX; ++q) triv[q] = 0u;
+  if (!keeper) {
+    if (gl == 0) {
+      const double p_uu0 = a.p_uu[wi];
+      wconst[0] = p_uu0;
+      wconst[1] = 1.0 - p_uu0;
+      wconst[2] = a.eqp[wi];
+      wconst[3] = a.eqp_w[wi] * (double)N;
+    }
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const int i = gl + G * q;
+      triv[q] = (i < K) ? a.tri[i] : 0u;
+      if (i < N) {
+        tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
+        dobs[i] = a.D[wN + i];  // phase-A observations (dmode 0); bootstraps use abn_fit_kernel
+      }
     }
   }
   __syncthreads();
-
-  double vx[5], c[5];
-  {
-    const double* s0 = a.simplex0 + (size_t)chain * 20;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) vx[k] = s0[4 * k + dim];
-  }
 
 #ifdef ABN_STAMPS
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 #endif
   auto eval = [&](double xd) -> double {
-    ABN_STAMP(6);  // Nelder-Mead bookkeeping + candidate since the exchange
+    ABN_STAMP(6);  // control flow + candidate fetch since the exchange
     const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
     const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
     const Gen Gm = genmatrix(al, be);
@@ -909,11 +921,12 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
     return acc;
   };
 
-  // exchange: every wavefront publishes its cost, one workgroup barrier, everybody reads all three
+  // exchange: every evaluation wavefront publishes its cost, one workgroup barrier, everybody reads all three.
+  // The barrier also hands the keeper's LDS writes (candidate table, shrink points) to the others.
   int phase = 0;
   auto exchange = [&](double f, double& f0, double& f1, double& f2) {
     double* buf = xch + 4 * phase;
-    if (gl == 0) buf[wv] = f;
+    if (!keeper && gl == 0) buf[wv] = f;
     __syncthreads();
     f0 = buf[0];
     f1 = buf[1];
@@ -922,21 +935,18 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
     ABN_STAMP(4);
   };
 
-  int st = ST_REFLECT;
-  int iter = 0, evals = 0;
-  double x0 = 0.0, xr = 0.0, bx = __builtin_nan("");
-  double best_cost = __builtin_inf();
+  // ---- control state, replicated in all four wavefronts and updated by the same code from the same costs
+  double c[5], best_cost = __builtin_inf();
   bool have_best = false;
-  int fin_status = 2;
-
-  auto begin_iteration = [&](bool count_iter) {
+  int iter = 0;
+  // IterState::update() + terminate_internal(): -1 = go on, else the ABN_FIT_* status.  `improved`: the best
+  // vertex is the new best_param (the keeper copies it)
+  auto ctl_begin = [&](bool count_iter, bool& improved) -> int {
     const double c_best = c[0];
-    if (c_best < best_cost || (__builtin_isinf(c_best) && __builtin_isinf(best_cost) &&
-                               (__builtin_signbit(c_best) == __builtin_signbit(best_cost)))) {
-      bx = vx[0];
-      best_cost = c_best;
-      have_best = true;
-    }
+    improved = c_best < best_cost || (__builtin_isinf(c_best) && __builtin_isinf(best_cost) &&
+                                      (__builtin_signbit(c_best) == __builtin_signbit(best_cost)));
+    best_cost = improved ? c_best : best_cost;
+    have_best = have_best || improved;
     if (count_iter) ++iter;
     bool converged = false;
     if (!((c[4] - c[0]) > a.gap_tol)) {
@@ -954,106 +964,184 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
     if (converged) status = 0;
     else if (iter >= a.max_iters) status = 1;
     else if (best_cost <= -__builtin_inf()) status = 3;
-    const bool done = status >= 0;
-    fin_status = done ? (have_best ? status : 2) : fin_status;
-    double acc = vx[0];
-    acc = acc + vx[1];
-    acc = acc + vx[2];
-    acc = acc + vx[3];
-    x0 = acc * (1.0 / 4.0);
-    xr = x0 + (x0 - vx[4]) * 1.0;
-    st = done ? ST_DONE : ST_REFLECT;
+    return status;
   };
 
-  // One call site of the cost function: `mode` (uniform over the workgroup) says what the three wavefronts
-  // evaluate this trip.  M_INIT1/2: Solver::init's five start costs (3 + 2); M_ITER: reflection, expansion,
-  // contraction; M_SHR1/2: NelderMead::shrink's four re-evaluations (3 + 1).
-  constexpr int M_INIT1 = 0, M_INIT2 = 1, M_ITER = 2, M_SHR1 = 3, M_SHR2 = 4, M_DONE = 5;
-  int mode = M_INIT1;
-  double x_e = 0.0, x_c = 0.0;
-  while (mode != M_DONE) {
-    double cand;
-    if (mode == M_INIT1) cand = wv == 0 ? vx[0] : (wv == 1 ? vx[1] : vx[2]);
-    else if (mode == M_INIT2) cand = wv == 0 ? vx[3] : vx[4];
-    else if (mode == M_ITER) {
-      x_e = x0 + (xr - x0) * 2.0;        // x0 + (xr - x0) * gamma
-      x_c = x0 + (vx[4] - x0) * 0.5;     // x0 + (xw - x0) * rho
-      cand = wv == 0 ? xr : (wv == 1 ? x_e : x_c);
-    } else if (mode == M_SHR1) cand = wv == 0 ? vx[1] : (wv == 1 ? vx[2] : vx[3]);
-    else cand = vx[4];
-    double f0, f1, f2;
-    exchange(eval(cand), f0, f1, f2);
-    bool start_shrink = false, sorted_begin = false;
-    if (mode == M_INIT1) {
-      c[0] = f0;
-      c[1] = f1;
-      c[2] = f2;
-      mode = M_INIT2;
-    } else if (mode == M_INIT2) {
-      c[3] = f0;
-      c[4] = f1;
-      evals = 5;
-      sort5(c, vx);
-      begin_iteration(false);
-      mode = (st == ST_DONE) ? M_DONE : M_ITER;
-    } else if (mode == M_ITER) {
-      // wave-uniform branches (measured: faster than the predicated form of abn_fit_kernel for a lone chain)
-      const double fr = f0, fe = f1, fc = f2;
-      if (fr < c[3] && fr >= c[0]) {          // reflection accepted
-        evals += 1;
-        c[4] = fr;
-        vx[4] = xr;
-        insert_tail<4>(c, vx);
-        sorted_begin = true;
-      } else if (fr < c[0]) {                 // expansion
-        evals += 2;
-        const bool take_e = fe < fr;
-        c[4] = take_e ? fe : fr;
-        vx[4] = take_e ? x_e : xr;
-        insert_tail<4>(c, vx);
-        sorted_begin = true;
-      } else if (fr >= c[3]) {                // contraction
-        evals += 2;
-        if (fc < c[4]) {
-          c[4] = fc;
-          vx[4] = x_c;
-          insert_tail<4>(c, vx);
-          sorted_begin = true;
-        } else if (a.shrink_variant) {
-          start_shrink = true;
-        } else {                              // argmin 0.8.1: rejected contraction leaves the simplex
-          if (a.no_skip == 0) {               // ... for good: finish the chain (FitArgs::no_skip)
-            const int rest = a.max_iters - iter - 1;
-            evals += 2 * rest;
-            iter += rest;
-            if (a.skipped && wv == 0 && gl == 0 && rest > 0) atomicAdd(a.skipped, 2ull * (unsigned long long)rest);
-          }
-          sorted_begin = true;
-        }
-      } else {                                // NaN reflection cost
-        evals += 1;
-        start_shrink = true;
-      }
-      if (start_shrink) {
+  // ---- keeper state: the simplex, this lane's dimension of the five vertices in rank order, the three
+  // candidates of the running iteration, best_param, evaluation count
+  double vx[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, xr = 0.0, x_e = 0.0, x_c = 0.0, bx = __builtin_nan("");
+  double dummy[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // evaluation wavefronts sort costs only
+  int evals = 0;
+  const double* s0 = a.simplex0 + (size_t)chain * 20;
+  if (keeper) {
 #pragma unroll
-        for (int k = 1; k < 5; ++k) vx[k] = vx[0] + (vx[k] - vx[0]) * 0.5;
-        mode = M_SHR1;
+    for (int k = 0; k < 5; ++k) vx[k] = s0[4 * k + dim];
+  }
+  // the keeper's lane group: quad q < 10 works on outcome q = (accepted point, rank): r@0..3, e@0, c@0..4
+  const int oq = gl >> 2;
+  const int o_kind = oq < 4 ? 0 : (oq == 4 ? 1 : 2);
+  const int o_rank = oq < 4 ? oq : (oq == 4 ? 0 : oq - 5);
+
+  // ---- Solver::init: the five start costs in input order (3 + 2), stable sort, first termination check
+  double cand = keeper ? 0.0 : s0[4 * wv + dim];
+  double f0, f1, f2;
+  exchange(keeper ? 0.0 : eval(cand), f0, f1, f2);
+  c[0] = f0;
+  c[1] = f1;
+  c[2] = f2;
+  cand = keeper ? 0.0 : s0[4 * (wv == 0 ? 3 : 4) + dim];
+  exchange(keeper ? 0.0 : eval(cand), f0, f1, f2);
+  c[3] = f0;
+  c[4] = f1;
+  evals = 5;
+  if (keeper) sort5(c, vx);
+  else sort5(c, dummy);
+  bool improved;
+  int status = ctl_begin(false, improved);
+  if (keeper && improved) bx = vx[0];
+  bool publish = true;  // the keeper hands the candidates of a freshly sorted simplex over directly
+  int par = 0;
+
+  while (status < 0) {
+    if (publish) {
+      if (keeper) {  // centroid (p0 + p1 + p2 + p3) * (1/4), x0 + (x0 - xw) * alpha, x0 + (xr - x0) * gamma, x0 + (xw - x0) * rho
+        double acc = vx[0];
+        acc = acc + vx[1];
+        acc = acc + vx[2];
+        acc = acc + vx[3];
+        const double x0 = acc * (1.0 / 4.0);
+        xr = x0 + (x0 - vx[4]) * 1.0;
+        x_e = x0 + (xr - x0) * 2.0;
+        x_c = x0 + (vx[4] - x0) * 0.5;
+        if (gl < 4) {
+          double* t = tab + par * kSpecTabDoubles;
+          t[dim] = xr;
+          t[4 + dim] = x_e;
+          t[8 + dim] = x_c;
+        }
       }
-      if (sorted_begin) {
-        begin_iteration(true);
-        mode = (st == ST_DONE) ? M_DONE : M_ITER;
+      __syncthreads();
+      if (!keeper) cand = tab[par * kSpecTabDoubles + 4 * wv + dim];
+      par ^= 1;
+      publish = false;
+    }
+    if (keeper) {
+      // the candidates of the NEXT iteration for each way this one can end.  Outcome (A, p): the accepted
+      // point A replaces the worst vertex and sorts in at rank p; the new order is v0..v3 with A at p.
+      const double A = o_kind == 0 ? xr : (o_kind == 1 ? x_e : x_c);
+      const double e0 = o_rank == 0 ? A : vx[0];
+      const double e1 = o_rank == 1 ? A : (o_rank < 1 ? vx[0] : vx[1]);
+      const double e2 = o_rank == 2 ? A : (o_rank < 2 ? vx[1] : vx[2]);
+      const double e3 = o_rank == 3 ? A : (o_rank < 3 ? vx[2] : vx[3]);
+      const double xw = o_rank == 4 ? A : vx[3];
+      double acc = e0;
+      acc = acc + e1;
+      acc = acc + e2;
+      acc = acc + e3;
+      const double x0 = acc * (1.0 / 4.0);
+      const double nr = x0 + (x0 - xw) * 1.0;
+      const double ne = x0 + (nr - x0) * 2.0;
+      const double nc = x0 + (xw - x0) * 0.5;
+      if (oq < kSpecOutcomes) {
+        double* t = tab + par * kSpecTabDoubles + oq * 12;
+        t[dim] = nr;
+        t[4 + dim] = ne;
+        t[8 + dim] = nc;
       }
-    } else if (mode == M_SHR1) {
+    }
+    double fr, fe, fc;
+    exchange(keeper ? 0.0 : eval(cand), fr, fe, fc);
+    // ---- NelderMead::next_iter's decision.  Every lane holds the same costs, so the branches are uniform.
+    // (Measured alternatives, both slower on a lone wavefront: the costs in scalar registers via
+    // v_readfirstlane — SGPR spills —, and the flat predicated form of abn_fit_kernel.)
+    int kind, which = 0;   // kind 0: a point is accepted, 1: rejected contraction (simplex untouched), 2: shrink
+    double fi = fr;
+    int spent;             // cost() calls the reference makes in this branch
+    if (fr < c[3] && fr >= c[0]) {          // reflection accepted
+      kind = 0;
+      spent = 1;
+    } else if (fr < c[0]) {                 // expansion tried
+      kind = 0;
+      spent = 2;
+      const bool take_e = fe < fr;
+      which = take_e ? 1 : 0;
+      fi = take_e ? fe : fr;
+    } else if (fr >= c[3]) {                // contraction tried
+      spent = 2;
+      if (fc < c[4]) {
+        kind = 0;
+        which = 2;
+        fi = fc;
+      } else {
+        kind = a.shrink_variant ? 2 : 1;
+      }
+    } else {                                // NaN reflection cost
+      kind = 2;
+      spent = 1;
+    }
+    evals += spent;
+    if (kind == 0) {
+      // rank of the accepted point: the stable insertion of insert_tail<4>
+      const bool b3 = fi < c[3], b2 = b3 && (fi < c[2]), b1 = b2 && (fi < c[1]), b0 = b1 && (fi < c[0]);
+      const int p = 4 - ((b3 ? 1 : 0) + (b2 ? 1 : 0) + (b1 ? 1 : 0) + (b0 ? 1 : 0));
+      c[4] = fi;
+      if (keeper) {
+        vx[4] = which == 0 ? xr : (which == 1 ? x_e : x_c);
+        insert_tail<4>(c, vx);
+      } else {
+        insert_tail<4>(c, dummy);
+      }
+      status = ctl_begin(true, improved);
+      if (keeper && improved) bx = vx[0];
+      ABN_STAMP(5);  // decision, cost insert, termination
+      if (status < 0) {
+        const int o = which == 0 ? p : (which == 1 ? 4 : 5 + p);
+        const double* t = tab + par * kSpecTabDoubles + o * 12;
+        if (keeper) {
+          xr = t[dim];
+          x_e = t[4 + dim];
+          x_c = t[8 + dim];
+        } else {
+          cand = t[4 * wv + dim];
+        }
+        par ^= 1;
+      }
+    } else if (kind == 1) {
+      // argmin 0.8.1: a rejected contraction leaves the simplex untouched — for good: every later iteration
+      // repeats this one.  no_skip == 0: finish the chain with the counters it would reach (FitArgs::no_skip)
+      if (a.no_skip == 0) {
+        const int rest = a.max_iters - iter - 1;
+        evals += 2 * rest;
+        iter += rest;
+        if (a.skipped && keeper && gl == 0 && rest > 0) atomicAdd(a.skipped, 2ull * (unsigned long long)rest);
+      }
+      status = ctl_begin(true, improved);
+      par ^= 1;  // same candidates again; the keeper rebuilds the (identical) table in the other buffer
+    } else {
+      // NelderMead::shrink (NaN reflection cost, or the textbook variant after a rejected contraction):
+      // vertices 1..4 move towards the best by sigma and are re-evaluated in order (3 + 1)
+      if (keeper) {
+#pragma unroll
+        for (int k = 1; k < 5; ++k) {
+          vx[k] = vx[0] + (vx[k] - vx[0]) * 0.5;
+          if (gl < 4) pts[4 * (k - 1) + dim] = vx[k];
+        }
+      }
+      __syncthreads();
+      if (!keeper) cand = pts[4 * wv + dim];
+      exchange(keeper ? 0.0 : eval(cand), f0, f1, f2);
       c[1] = f0;
       c[2] = f1;
       c[3] = f2;
-      mode = M_SHR2;
-    } else {  // M_SHR2
+      if (!keeper) cand = pts[12 + dim];
+      exchange(keeper ? 0.0 : eval(cand), f0, f1, f2);
       c[4] = f0;
       evals += 4;
-      sort5(c, vx);
-      begin_iteration(true);
-      mode = (st == ST_DONE) ? M_DONE : M_ITER;
+      if (keeper) sort5(c, vx);
+      else sort5(c, dummy);
+      status = ctl_begin(true, improved);
+      if (keeper && improved) bx = vx[0];
+      publish = true;
     }
   }
 
@@ -1064,14 +1152,14 @@ __global__ __launch_bounds__(3 * kWave) void abn_fit_spec_kernel(const FitArgs a
   }
 #endif
   const double b0 = dpp_mov<kDppQuadBcast0>(bx), b1 = dpp_mov<kDppQuadBcast1>(bx);
-  if (wv == 0) {
+  if (keeper) {
     if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
     if (gl == 0) {
       FitInfoDev fo;
       fo.best_cost = best_cost;
       fo.iters = iter;
       fo.evals = evals;
-      fo.status = fin_status;
+      fo.status = have_best ? status : 2;
       fo.lanes = G;
       a.info[chain] = fo;
     }

@@ -37,8 +37,8 @@ for lanes in (16, 64):
 
 # speculative three-wavefront kernel (phase A): wavefront 0 of chain 0, per ITERATION
 L.abn_plan_debug_stamps_spec.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
-names = ["P1 bcast+genmatrix+puu", "P2 power table", "P3 triples", "P4+P5 rows, reduce", "exchange (LDS + barrier)", "-",
-         "P6 NM update + candidates", "iters"]
+names = ["P1 bcast+genmatrix+puu", "P2 power table", "P3 triples", "P4+P5 rows, reduce", "exchange (LDS + barrier)",
+         "decision, cost insert, termination", "candidate fetch, loop head", "iters"]
 plan = A.Plan(ctx, ped[:, :3], 1, 1, 0, options=A.default_options())
 plan.set_windows(ped[:, 3][None, :], np.array([p0]))
 out = (C.c_uint64 * 8)()

@@ -622,6 +622,40 @@ def test_fixed_point_skip_changes_no_output(abn, gpu_ctx, golden, oracle):
         _assert_fits_equal(res[0][0], res[0][1], want)
 
 
+@pytest.mark.parametrize("variant,no_skip,iters", ((1, 0, 10000), (0, 1, 400), (0, 0, 10000)))
+def test_speculative_phase_a_all_branches(abn, gpu_ctx, golden, oracle, variant, no_skip, iters):
+    """Phase A of a small plan runs on abn_fit_spec_kernel (three evaluation wavefronts + the keeper).  Its
+    rare branches — NelderMead::shrink after a NaN reflection cost or, in the textbook variant, after a
+    rejected contraction; the repeated iterations of a stuck fit — must follow the oracle bit for bit."""
+    ped, p0 = golden["generated"], golden["p0uu_generated"]
+    W, S, seed = 5, 40, 91
+    rng = np.random.default_rng(8)
+    D = np.abs(ped[:, 3][None, :] * rng.uniform(0.7, 1.3, (W, 1)))
+    D[3, 2] = np.nan                      # every cost of window 3 is NaN: a shrink per iteration
+    p0w = rng.uniform(0.6, 0.8, W)
+    o = abn.default_options(seed=seed, shrink_on_failed_contraction=variant, no_fixed_point_skip=no_skip,
+                            max_iters_start=iters)
+    plan = abn.Plan(gpu_ctx, ped[:, :3], W, S, 0, options=o)
+    plan.set_windows(D, p0w)
+    plan.run_phase(0)
+    out = plan.download()
+    plan.close()
+    assert int(out["info_a"]["lanes"][0, 0]) == 64
+    assert out["best_start"][3] == -1 and np.all(out["info_a"]["status"][3] == 2)
+    for w in range(W):
+        pw = np.concatenate([ped[:, :3], D[w][:, None]], axis=1)
+        mx = D[w].max() if w != 3 else np.nanmax(D[w])
+        s0 = abn.gen_start_simplices(seed, w, S, float(np.fmax.reduce(D[w])))
+        fits = oracle.fit_batch(pw, p0w[w], p0w[w], 1.0, s0, iters, shrink_variant=variant, lanes=64)
+        for k in ("status", "iters", "evals"):
+            assert np.array_equal(out["info_a"][w][k], fits[k]), (w, k)
+        ok = fits["status"] != 2
+        assert np.array_equal(out["info_a"][w]["best_cost"][ok], fits["best_cost"][ok])
+        if w != 3:
+            k, model, _, _, _ = oracle.select_best(pw, p0w[w], fits["best"])
+            assert out["best_start"][w] == k and np.array_equal(out["models"][w], model)
+
+
 def test_reference_unit_tests_through_the_cpp_mirror(abn, gpu_ctx):
     """The reference's enabled unit tests on the path (same_as_r, test_cost_function, build_pedigree) restated
     against the C++ mirror of its API and executed on the GPU (alphabeta_rs_amd/host/reference_tests.cpp).
