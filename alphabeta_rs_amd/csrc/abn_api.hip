@@ -136,6 +136,8 @@ static int upload_topology(abn_ctx* c, const Topology& t, DevTopology& d) {
 // ------------------------------------------------------------------------------------------------
 constexpr size_t kMaxDynLds = 64 * 1024;
 constexpr size_t kLdsResidentMax = 40 * 1024;
+constexpr long long kPhaseASpecMax = 1024;  // start chains up to which phase A uses abn_fit_spec_kernel
+constexpr long long kPhaseAWideMax = 6144;  // ... and up to which it uses one wavefront per chain
 constexpr int kPhaseACap = 1000;  // first-pass iteration cap of the two-pass phase A  // above this the fit kernel streams rows instead of staging them
 
 // Lanes of a wavefront per chain.  Auto: by pedigree rows, then widened until the workgroup's LDS
@@ -639,7 +641,11 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   }
   p->lanes = pick_lanes(n_rows, p->opt.lanes_per_chain, p->topo.chain_stride);
   p->lanes_a = p->lanes;
-  if (p->opt.lanes_per_chain == 0 && (long long)n_windows * n_starts <= 2048) p->lanes_a = 64;
+  // Phase A is latency-bound while its chains fit the machine about twice over (3 wavefronts x 1024 SIMDs): one
+  // wavefront per chain then beats packing several chains into a wavefront, and below ~1000 chains the
+  // four-wavefront speculative kernel beats both (scripts/phase_a_sweep.py, C3 topology: 1000 chains 3.2 / 3.4 /
+  // 5.1 ms for speculative / 64 lanes / 16 lanes; 4000 chains - / 5.2 / 6.6 ms; 8000 chains - / 7.7 / 7.0 ms)
+  if (p->opt.lanes_per_chain == 0 && (long long)n_windows * n_starts <= kPhaseAWideMax) p->lanes_a = 64;
   if ((size_t)(kWave / p->lanes) * p->topo.chain_stride * sizeof(double) > kMaxDynLds ||
       ((size_t)p->topo.chain_stride + kSelChunk) * sizeof(double) > kMaxDynLds) {
     delete p;
@@ -675,10 +681,13 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   PALLOC(infoB, W * B);
   PALLOC(raw_own, W * B * 7);
   PALLOC(skipped, 2);
-  // Phase A with many chains: 7 % of random starts never reach SD < EPSILON and run all 10000 iterations; in
-  // one launch such a chain may be dispatched late and then runs alone for tens of milliseconds.  Two passes:
-  // every chain for at most kPhaseACap iterations, then the unfinished ones, compacted, all resident at once.
-  p->twopass_a = (long long)n_windows * n_starts > 4096 && p->opt.max_iters_start > kPhaseACap;
+  // Phase A with many chains when the repetitions of stuck fits must be executed (no_fixed_point_skip): 7 % of
+  // random starts run into argmin's fixed point and repeat it up to iteration 10000; dispatched late in one launch
+  // such a chain runs alone for tens of milliseconds.  Two passes: every chain for at most kPhaseACap iterations,
+  // then the unfinished ones, compacted, all resident at once.  With the default skip those chains end at once and
+  // one pass is faster (metaprofile shape, 30000 start chains: 14.6 ms against 18.3 ms).
+  p->twopass_a = (long long)n_windows * n_starts > 4096 && p->opt.max_iters_start > kPhaseACap &&
+                 p->opt.no_fixed_point_skip != 0 && p->opt.shrink_on_failed_contraction == 0;
   if (p->twopass_a) {
     PALLOC(nm_state, W * S * 32);
     PALLOC(susp_list, W * S + 1);
@@ -793,7 +802,7 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   if (timed) HIPCHK(c, hipEventRecord(p->ev[0], st));
   // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once,
   // a fourth keeps the simplex and prepares the next candidates meanwhile (abn_fit_spec_kernel)
-  const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && (long long)wn * p->S <= 2048 &&
+  const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && (long long)p->W * p->S <= kPhaseASpecMax &&
                     spec_applicable(a);
   int rc;
   if (spec) {
