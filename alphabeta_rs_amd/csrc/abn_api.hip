@@ -892,14 +892,18 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   return ABN_OK;
 }
 
-extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
-  if (!p) return ABN_ERR_INVALID_ARG;
+// zero_skipped: bit 0 / bit 1 = clear the phase-A / phase-B counter of skipped evaluations before the launch
+static int plan_run_phase(abn_plan* p, int32_t phase, int zero_skipped) {
   abn_ctx* c = p->ctx;
   if (!p->windows_set) return set_err(c, ABN_ERR_STATE, "abn_plan_set_windows has not been called");
   HIPCHK(c, hipSetDevice(c->device));
+  if (zero_skipped == 3) {
+    HIPCHK(c, hipMemsetAsync(p->skipped.p, 0, 2 * sizeof(unsigned long long), c->stream));
+  } else if (zero_skipped) {
+    HIPCHK(c, hipMemsetAsync(p->skipped.p + (zero_skipped >> 1), 0, sizeof(unsigned long long), c->stream));
+  }
   if (phase == 0) {
     if (p->S <= 0) return set_err(c, ABN_ERR_STATE, "plan has no starts");
-    HIPCHK(c, hipMemsetAsync(p->skipped.p, 0, sizeof(unsigned long long), c->stream));
     int rc = enqueue_phase_a(p, 0, p->W, c->stream, true);
     if (rc) return rc;
     p->phase_a_done = true;
@@ -909,13 +913,17 @@ extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
   if (phase == 1) {
     if (p->B <= 0) return set_err(c, ABN_ERR_STATE, "plan has no bootstraps");
     if (!p->phase_a_done) return set_err(c, ABN_ERR_STATE, "phase A has not run");
-    HIPCHK(c, hipMemsetAsync(p->skipped.p + 1, 0, sizeof(unsigned long long), c->stream));
     int rc = enqueue_phase_b(p, 0, p->W, c->stream, true);
     if (rc) return rc;
     p->ran_b = true;
     return ABN_OK;
   }
   return set_err(c, ABN_ERR_INVALID_ARG, "phase must be 0 or 1");
+}
+
+extern "C" int abn_plan_run_phase(abn_plan* p, int32_t phase) {
+  if (!p) return ABN_ERR_INVALID_ARG;
+  return plan_run_phase(p, phase, phase == 0 ? 1 : 2);
 }
 
 // Whole pass.  opts.window_groups > 1 cuts the plan into contiguous window groups that run A -> select -> B
@@ -931,9 +939,9 @@ extern "C" int abn_plan_run(abn_plan* p) {
   groups = std::max(1, std::min(groups, p->W));
   if (groups == 1 || p->S <= 0 || p->B <= 0) {
     int rc = ABN_OK;
-    if (p->S > 0) rc = abn_plan_run_phase(p, 0);
+    if (p->S > 0) rc = plan_run_phase(p, 0, 3);  // one memset clears both skip counters
     if (rc) return rc;
-    if (p->B > 0) rc = abn_plan_run_phase(p, 1);
+    if (p->B > 0) rc = plan_run_phase(p, 1, p->S > 0 ? 0 : 2);
     return rc;
   }
   HIPCHK(c, hipSetDevice(c->device));
