@@ -136,6 +136,10 @@ static int upload_topology(abn_ctx* c, const Topology& t, DevTopology& d) {
 // ------------------------------------------------------------------------------------------------
 constexpr size_t kMaxDynLds = 64 * 1024;
 constexpr size_t kLdsResidentMax = 40 * 1024;
+#ifndef ABN_PERSIST_WAVES
+#define ABN_PERSIST_WAVES 3072
+#endif
+constexpr long long kPersistWaves = ABN_PERSIST_WAVES;  // wavefronts of a persistent launch: 3 per SIMD x 4 SIMDs x 256 CUs
 constexpr long long kPhaseASpecMax = 1024;  // start chains up to which phase A uses abn_fit_spec_kernel
 constexpr long long kPhaseAWideMax = 6144;  // ... and up to which it uses one wavefront per chain
 constexpr int kPhaseACap = 1000;  // first-pass iteration cap of the two-pass phase A  // above this the fit kernel streams rows instead of staging them
@@ -174,8 +178,19 @@ static hipError_t launch_fit_gt(const FitArgs& a, int rmax, dim3 grid, size_t ld
   return hipGetLastError();
 }
 template <int G>
-static hipError_t launch_fit_g(const FitArgs& a, int rmax, dim3 grid, size_t lds, hipStream_t s) {
+static hipError_t launch_fit_refill(const FitArgs& a, int rmax, dim3 grid, size_t lds, hipStream_t s) {
+  switch (rmax) {
+    case 1: hipLaunchKernelGGL((abn_fit_refill_kernel<G, 1>), grid, dim3(kWave), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((abn_fit_refill_kernel<G, 2>), grid, dim3(kWave), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((abn_fit_refill_kernel<G, 4>), grid, dim3(kWave), lds, s, a); break;
+    default: hipLaunchKernelGGL((abn_fit_refill_kernel<G, 8>), grid, dim3(kWave), lds, s, a); break;
+  }
+  return hipGetLastError();
+}
+template <int G>
+static hipError_t launch_fit_g(const FitArgs& a, int rmax, dim3 grid, size_t lds, hipStream_t s, bool refill) {
   const bool twopass = a.iter_cap > 0 || a.resume != 0;
+  if (refill) return launch_fit_refill<G>(a, rmax, grid, lds, s);
   return twopass ? launch_fit_gt<G, true>(a, rmax, grid, lds, s) : launch_fit_gt<G, false>(a, rmax, grid, lds, s);
 }
 
@@ -193,15 +208,21 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
   const size_t lds = (size_t)ng * (size_t)a.chain_stride * sizeof(double);
   if (lds > kMaxDynLds)
     return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS per workgroup than supported (T or K too large)");
-  const long long blocks = (chains + ng - 1) / ng;
-  if (blocks > 0x7fffffffLL) return set_err(c, ABN_ERR_INVALID_ARG, "too many chains for one launch");
+  long long blocks = (chains + ng - 1) / ng;
+  if (blocks > 0x7fffffffLL || chains > 0x7fffffffLL)
+    return set_err(c, ABN_ERR_INVALID_ARG, "too many chains for one launch");
+  // More wavefronts than the GPU holds at once and several chains per wavefront: the persistent kernel, whose
+  // groups take the next chain from a queue when their fit ends (abn_fit_refill_kernel)
+  const bool refill = a.queue != nullptr && rmax > 0 && ng > 1 && a.iter_cap == 0 && a.resume == 0 &&
+                      blocks > kPersistWaves;
+  if (refill) blocks = kPersistWaves;
   dim3 grid((unsigned)blocks);
   hipError_t e;
   switch (lanes) {
-    case 8: e = launch_fit_g<8>(a, rmax, grid, lds, st); break;
-    case 16: e = launch_fit_g<16>(a, rmax, grid, lds, st); break;
-    case 32: e = launch_fit_g<32>(a, rmax, grid, lds, st); break;
-    default: e = launch_fit_g<64>(a, rmax, grid, lds, st); break;
+    case 8: e = launch_fit_g<8>(a, rmax, grid, lds, st, refill); break;
+    case 16: e = launch_fit_g<16>(a, rmax, grid, lds, st, refill); break;
+    case 32: e = launch_fit_g<32>(a, rmax, grid, lds, st, refill); break;
+    default: e = launch_fit_g<64>(a, rmax, grid, lds, st, refill); break;
   }
   HIPCHK(c, e);
   return ABN_OK;
@@ -595,7 +616,8 @@ struct abn_plan {
   DevBuf<double> dstar;  // stream mode: materialised bootstrap observations [W x B x N]
   DevBuf<double> nm_state;    // two-pass phase A: parked Nelder-Mead states [W x S x 32]
   DevBuf<int> susp_list;      // [W x S] + 1 counter at the end
-  DevBuf<unsigned long long> skipped;  // [2] evaluations not executed (fixed-point skip) in phase A, phase B
+  // per phase (A, B): [2*ph] evaluations not executed (fixed-point skip), [2*ph+1] chain queue of the persistent kernel
+  DevBuf<unsigned long long> skipped;
   bool twopass_a = false;
   bool stream_b = false;
   double* raw = nullptr;  // raw_own.p or caller-bound
@@ -680,7 +702,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   PALLOC(bestB, W * B * 4);
   PALLOC(infoB, W * B);
   PALLOC(raw_own, W * B * 7);
-  PALLOC(skipped, 2);
+  PALLOC(skipped, 4);
   // Phase A with many chains when the repetitions of stuck fits must be executed (no_fixed_point_skip): 7 % of
   // random starts run into argmin's fixed point and repeat it up to iteration 10000; dispatched late in one launch
   // such a chain runs alone for tens of milliseconds.  Two passes: every chain for at most kPhaseACap iterations,
@@ -779,7 +801,7 @@ static void fill_common(const abn_plan* p, FitArgs& a) {
 
 // Phase A (starts) + selection for windows [w0, w0+wn) on stream st.  ev != nullptr: record the plan's
 // timing events around the kernels.
-static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool timed) {
+static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool timed, bool refill) {
   abn_ctx* c = p->ctx;
   const size_t N = (size_t)p->N, S = (size_t)p->S, o = (size_t)w0;
   FitArgs a{};
@@ -799,6 +821,7 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   a.info = p->infoA.p + o * S;
   a.raw = nullptr;
   a.skipped = p->skipped.p;
+  a.queue = refill ? reinterpret_cast<unsigned*>(p->skipped.p + 1) : nullptr;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[0], st));
   // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once,
   // a fourth keeps the simplex and prepares the next candidates meanwhile (abn_fit_spec_kernel)
@@ -853,7 +876,7 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
 }
 
 // Phase B (bootstraps) for windows [w0, w0+wn) on stream st
-static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool timed) {
+static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool timed, bool refill) {
   abn_ctx* c = p->ctx;
   const size_t N = (size_t)p->N, B = (size_t)p->B, o = (size_t)w0;
   FitArgs a{};
@@ -874,7 +897,8 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   a.best = p->bestB.p + o * B * 4;
   a.info = p->infoB.p + o * B;
   a.raw = p->raw + o * B * 7;
-  a.skipped = p->skipped.p + 1;
+  a.skipped = p->skipped.p + 2;
+  a.queue = refill ? reinterpret_cast<unsigned*>(p->skipped.p + 3) : nullptr;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[4], st));
   if (p->stream_b) {  // gather the bootstrap observations once per fit, then stream them
     double* dst = p->dstar.p + o * B * N;
@@ -892,19 +916,19 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   return ABN_OK;
 }
 
-// zero_skipped: bit 0 / bit 1 = clear the phase-A / phase-B counter of skipped evaluations before the launch
+// zero_skipped: bit 0 / bit 1 = clear the phase-A / phase-B skip counter and chain queue before the launch
 static int plan_run_phase(abn_plan* p, int32_t phase, int zero_skipped) {
   abn_ctx* c = p->ctx;
   if (!p->windows_set) return set_err(c, ABN_ERR_STATE, "abn_plan_set_windows has not been called");
   HIPCHK(c, hipSetDevice(c->device));
   if (zero_skipped == 3) {
-    HIPCHK(c, hipMemsetAsync(p->skipped.p, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(p->skipped.p, 0, 4 * sizeof(unsigned long long), c->stream));
   } else if (zero_skipped) {
-    HIPCHK(c, hipMemsetAsync(p->skipped.p + (zero_skipped >> 1), 0, sizeof(unsigned long long), c->stream));
+    HIPCHK(c, hipMemsetAsync(p->skipped.p + 2 * (zero_skipped >> 1), 0, 2 * sizeof(unsigned long long), c->stream));
   }
   if (phase == 0) {
     if (p->S <= 0) return set_err(c, ABN_ERR_STATE, "plan has no starts");
-    int rc = enqueue_phase_a(p, 0, p->W, c->stream, true);
+    int rc = enqueue_phase_a(p, 0, p->W, c->stream, true, true);
     if (rc) return rc;
     p->phase_a_done = true;
     p->ran_a = true;
@@ -913,7 +937,7 @@ static int plan_run_phase(abn_plan* p, int32_t phase, int zero_skipped) {
   if (phase == 1) {
     if (p->B <= 0) return set_err(c, ABN_ERR_STATE, "plan has no bootstraps");
     if (!p->phase_a_done) return set_err(c, ABN_ERR_STATE, "phase A has not run");
-    int rc = enqueue_phase_b(p, 0, p->W, c->stream, true);
+    int rc = enqueue_phase_b(p, 0, p->W, c->stream, true, true);
     if (rc) return rc;
     p->ran_b = true;
     return ABN_OK;
@@ -956,14 +980,14 @@ extern "C" int abn_plan_run(abn_plan* p) {
     HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     p->ev_join.push_back(e);
   }
-  HIPCHK(c, hipMemsetAsync(p->skipped.p, 0, 2 * sizeof(unsigned long long), c->stream));
+  HIPCHK(c, hipMemsetAsync(p->skipped.p, 0, 4 * sizeof(unsigned long long), c->stream));
   HIPCHK(c, hipEventRecord(p->ev_fork, c->stream));
   for (int g = 0; g < groups; ++g) {
     const int w0 = (int)((long long)p->W * g / groups), w1 = (int)((long long)p->W * (g + 1) / groups);
     hipStream_t st = c->side[(size_t)g];
     HIPCHK(c, hipStreamWaitEvent(st, p->ev_fork, 0));
-    int rc = enqueue_phase_a(p, w0, w1 - w0, st, g == 0);
-    if (!rc) rc = enqueue_phase_b(p, w0, w1 - w0, st, g == 0);
+    int rc = enqueue_phase_a(p, w0, w1 - w0, st, g == 0, false);  // groups share the plan's one queue: no
+    if (!rc) rc = enqueue_phase_b(p, w0, w1 - w0, st, g == 0, false);  // persistent kernel
     if (rc) return rc;
     HIPCHK(c, hipEventRecord(p->ev_join[(size_t)g], st));
   }
@@ -1044,7 +1068,7 @@ extern "C" int abn_plan_counters(abn_plan* p, int64_t* out5) {
     h.resize(b.n);
     unsigned long long sk = 0;
     HIPCHK(c, hipMemcpyAsync(h.data(), b.p, b.bytes(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&sk, p->skipped.p + phase, sizeof sk, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&sk, p->skipped.p + 2 * phase, sizeof sk, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (const auto& f : h) {
       out4[0] += 1;

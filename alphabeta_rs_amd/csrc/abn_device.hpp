@@ -101,6 +101,7 @@ struct FitArgs {
   // as running the repetitions.  The evaluations not executed are summed into *skipped (nullable).
   int no_skip;
   unsigned long long* skipped;
+  unsigned* queue;       // abn_fit_refill_kernel: next chain to start (zeroed by the host); nullptr = no persistent launch
   double sd_tol;
   double gap_tol;        // 64 * sd_tol, precomputed on the host so that it stays a scalar (kernarg) operand
   // outputs (fit order)
@@ -793,6 +794,307 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
       if (gl == 4) ro[4] = est_mm(b0, b1);
       if (gl == 5) ro[5] = est_um(b0, b1);
       if (gl == 6) ro[6] = p_uu_est(b0, b1);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent variant of the resident fit kernel for launches with many more chains than the GPU holds
+// wavefronts (phase B of a multi-window shard, phase A of the metaprofile shape).  Chains differ in length
+// (300 ... 900 evaluations on C3), so in abn_fit_kernel a wavefront lives as long as the longest of its 64/G
+// chains and its other groups idle: 1.29x the wavefront-steps the chains need.  Here the grid is one resident
+// set of wavefronts; a group whose fit ends writes its results and takes the next chain from an atomic queue
+// (`FitArgs::queue`, zeroed by the host; initial chains are the slots themselves), so every group stays busy
+// until the queue is empty.  Solver::init's five start evaluations become states of the evaluation-synchronous
+// machine (ST_INIT0..4) so that a freshly started chain runs next to chains in mid-flight.
+// Every chain computes exactly what it computes in abn_fit_kernel (same code for the evaluation, the same
+// Nelder-Mead update), and results are written by chain index: outputs are bit-identical and independent
+// of the schedule.  Resident mode only (RMAX > 0), single pass.
+// ------------------------------------------------------------------------------------------------
+constexpr int ST_IDLE = 13;
+
+template <int G, int RMAX>
+__global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs a) {
+  static_assert(RMAX > 0, "resident mode only");
+  constexpr int NG = kWave / G;
+  constexpr int RR = RMAX;
+  extern __shared__ __align__(16) double lds[];
+
+  const int lane = threadIdx.x;
+  const int g = lane / G;
+  const int gl = lane - g * G;
+  const int dim = gl & 3;
+  const unsigned total = (unsigned)((long long)a.W * a.C);
+  const int N = a.N, K = a.K, TP = a.TP;
+
+  double* pw = lds + (size_t)g * a.chain_stride;
+  double* dtab = pw + 9 * TP;
+  double* wconst = dtab + ((K + 1) & ~1);                                 // p0uu, p0mm, eqp, eqp_weight*N
+  double* dobs = wconst + 4;                                              // N doubles
+  uint32_t* tri_s = reinterpret_cast<uint32_t*>(dobs + ((N + 1) & ~1));  // this group's copy of the triple list
+
+  // ---- per-group constants of the topology: triple list in LDS, this lane's row -> triple ids in registers
+  uint32_t tidp[(RR + 1) / 2];
+  for (int t = gl; t < K; t += G) tri_s[t] = a.tri[t];
+#pragma unroll
+  for (int q = 0; q < (RR + 1) / 2; ++q) tidp[q] = 0u;
+#pragma unroll
+  for (int q = 0; q < RR; ++q) {
+    const int i = gl + G * q;
+    if (i < N) tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
+  }
+
+  // ---- per-chain state
+  unsigned chain = blockIdx.x * NG + g;
+  double vx[5], c[5];
+  int st = ST_IDLE;
+  int iter = 0, evals = 0;
+  double xc = 0.0, x0 = 0.0, xr = 0.0, bx = __builtin_nan("");
+  double fr = 0.0, best_cost = __builtin_inf();
+  bool have_best = false;
+  int fin_status = 2;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    vx[k] = 0.0;
+    c[k] = 0.0;
+  }
+
+  // start chain `chain` in this group: window constants and observed divergences (bootstrap: gathered through
+  // the index row, src/boot_model.rs:50-54) to LDS, start simplex, fresh optimiser state
+  auto setup_chain = [&]() {
+    const int w = (int)(chain / (unsigned)a.C);
+    const int j = (int)(chain - (unsigned)w * (unsigned)a.C);
+    const int wi = w * a.wstride;
+    const size_t wN = (size_t)w * (size_t)N;
+    if (gl == 0) {
+      const double p_uu0 = a.p_uu[wi];
+      wconst[0] = p_uu0;
+      wconst[1] = 1.0 - p_uu0;                          // p0mm, src/ab_neutral.rs:23
+      wconst[2] = a.eqp[wi];
+      wconst[3] = a.eqp_w[wi] * (double)N;              // eqp_weight * nrows, src/structs.rs:210-211
+    }
+    const uint32_t* idx_row = a.idx + (size_t)chain * (size_t)N;
+    const size_t dN = (a.dmode == 2) ? (size_t)chain * (size_t)N : wN;
+#pragma unroll
+    for (int q = 0; q < RR; ++q) {
+      const int i = gl + G * q;
+      if (i < N)
+        dobs[i] = (a.dmode == 1) ? a.pred[wN + i] + a.resid[wN + idx_row[i]] : a.D[dN + i];
+    }
+    if (a.smode == 0) {
+      const double* s0 = a.simplex0 + (size_t)chain * 20;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) vx[k] = s0[4 * k + dim];
+    } else {  // [params, vary() x4], src/boot_model.rs:69-75
+      const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+      const uint32_t wg = a.window_offset + (uint32_t)w, bg = a.boot_offset + (uint32_t)j;
+      vx[0] = a.model[4 * w + dim];
+#pragma unroll
+      for (int v = 1; v < 5; ++v) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)(v - 1) * 2u + (uint32_t)(dim >> 1), bg, wg, kTagJitter, k0, k1, r);
+        const uint32_t r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        const bool odd = (dim & 1) != 0;
+        vx[v] = vary_one(vx[0], odd ? r2 : r0, odd ? r3 : r1);
+      }
+    }
+    iter = 0;
+    evals = 0;
+    bx = __builtin_nan("");
+    best_cost = __builtin_inf();
+    have_best = false;
+    fin_status = 2;
+    fr = 0.0;
+    st = ST_INIT0;
+  };
+  if (chain < total) setup_chain();
+  __syncthreads();
+
+  // ---- one cost evaluation (as abn_fit_kernel, resident mode)
+  auto eval = [&](double xd) -> double {
+    const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
+    const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
+    const Gen Gm = genmatrix(al, be);                        // P1
+    const double p_mm = wconst[1];
+    const double sv0 = wconst[0], sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;  // src/divergence.rs:44
+    const double puu = p_uu_est(al, be);                     // src/divergence.rs:92
+    const double dq = puu - wconst[2];
+    const double pen = wconst[3] * (dq * dq);                // src/structs.rs:210-212
+    build_power_table<G>(Gm, a.T, TP, pw, gl);               // P2
+    __syncthreads();
+#pragma unroll 1
+    for (int t = gl; t < K; t += G) dtab[t] = triple_dt(tri_s[t], pw, TP, sv0, sv1, sv2);  // P3
+    __syncthreads();
+    double acc = 0.0;                                        // P4
+    constexpr int RC = RR < 8 ? RR : 8;
+#pragma unroll
+    for (int q0 = 0; q0 < RR; q0 += RC) {
+      double dv[RC], tv[RC];
+#pragma unroll
+      for (int q = 0; q < RC; ++q) {
+        const int i = gl + G * (q0 + q);
+        dv[q] = dobs[i < N ? i : N - 1];
+        tv[q] = dtab[(tidp[(q0 + q) / 2] >> (16 * ((q0 + q) & 1))) & 0xffffu];
+      }
+#pragma unroll
+      for (int q = 0; q < RC; ++q) {
+        const double r = dv[q] - ic - tv[q];
+        const double term = r * r + pen;
+        acc = acc + (((gl + G * (q0 + q)) < N) ? term : 0.0);
+      }
+    }
+    acc = group_sum_dpp<G>(acc);                             // P5
+    __syncthreads();
+    return acc;
+  };
+
+  // IterState::update() + terminate_internal() + the head of next_iter (centroid, reflection); as abn_fit_kernel
+  auto begin_iteration = [&](bool count_iter) {
+    const double c_best = c[0];
+    if (c_best < best_cost || (__builtin_isinf(c_best) && __builtin_isinf(best_cost) &&
+                               (__builtin_signbit(c_best) == __builtin_signbit(best_cost)))) {
+      bx = vx[0];
+      best_cost = c_best;
+      have_best = true;
+    }
+    if (count_iter) ++iter;
+    bool converged = false;
+    if (!((c[4] - c[0]) > a.gap_tol)) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) sum = sum + c[k];
+      const double c0 = sum / 5.0;
+      double ss = 0.0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) ss = ss + (c[k] - c0) * (c[k] - c0);
+      const double sd = __builtin_sqrt(1.0 / (5.0 - 1.0) * ss);
+      converged = sd < a.sd_tol;
+    }
+    int status = -1;
+    if (converged) status = 0;
+    else if (iter >= a.max_iters) status = 1;
+    else if (best_cost <= -__builtin_inf()) status = 3;
+    const bool done = status >= 0;
+    fin_status = done ? (have_best ? status : 2) : fin_status;
+    double acc = vx[0];
+    acc = acc + vx[1];
+    acc = acc + vx[2];
+    acc = acc + vx[3];
+    x0 = acc * (1.0 / 4.0);
+    xr = x0 + (x0 - vx[4]) * 1.0;
+    xc = xr;
+    st = done ? ST_DONE : ST_REFLECT;
+  };
+
+  while (__ballot(st != ST_IDLE) != 0ull) {
+    const bool in_init = st < ST_REFLECT;                         // Solver::init: start vertex st - ST_INIT0
+    const double f = eval(in_init ? vx[0] : xc);
+    // ---- decisions of NelderMead::next_iter as predicates (inert for groups in init or idle)
+    const bool is_ref = st == ST_REFLECT, is_exp = st == ST_EXPAND, is_con = st == ST_CONTRACT;
+    const bool active = is_ref || is_exp || is_con;
+    const bool acc_r = is_ref && (f < c[3]) && (f >= c[0]);
+    const bool go_exp = is_ref && !acc_r && (f < c[0]);
+    const bool go_con = is_ref && !acc_r && !go_exp && (f >= c[3]);
+    const bool nan_ref = is_ref && !acc_r && !go_exp && !go_con;
+    const bool keep_r = is_exp && !(f < fr);
+    const bool acc_c = is_con && (f < c[4]);
+    const bool rej_c = is_con && !acc_c;
+    const bool do_insert = acc_r || is_exp || acc_c;
+    const bool start_shrink = nan_ref || (rej_c && a.shrink_variant != 0);
+    const bool do_begin = do_insert || (rej_c && a.shrink_variant == 0);
+    evals += active ? 1 : 0;
+    if (rej_c && a.shrink_variant == 0 && a.no_skip == 0) {  // fixed point: finish the chain (FitArgs::no_skip)
+      const int rest = a.max_iters - iter - 1;
+      evals += 2 * rest;
+      iter += rest;
+      if (a.skipped && gl == 0 && rest > 0) atomicAdd(a.skipped, 2ull * (unsigned long long)rest);
+    }
+    const double xi = keep_r ? xr : xc;
+    const double fi = keep_r ? fr : f;
+    fr = is_ref ? f : fr;
+    const double x_e = x0 + (xr - x0) * 2.0;
+    const double x_c = x0 + (vx[4] - x0) * 0.5;
+    xc = go_exp ? x_e : (go_con ? x_c : xc);
+    st = go_exp ? ST_EXPAND : (go_con ? ST_CONTRACT : st);
+    if (do_insert) {
+      c[4] = fi;
+      vx[4] = xi;
+      insert_tail<4>(c, vx);
+    }
+    if (do_begin) begin_iteration(true);
+    // ---- Solver::init: costs in input order; the arrays rotate so that no register array is indexed at run time
+    if (in_init) {
+      const double tv = vx[0];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        c[q] = c[q + 1];
+        vx[q] = vx[q + 1];
+      }
+      c[4] = f;
+      vx[4] = tv;
+      st = st + 1;
+      if (st == ST_REFLECT) {  // all five: stable sort, first termination check
+        evals = 5;
+        sort5(c, vx);
+        begin_iteration(false);
+      }
+    }
+    // ---- NelderMead::shrink (rare; the other groups idle)
+    if (__ballot(start_shrink) != 0ull) {
+#pragma unroll 1
+      for (int k = 1; k < 5; ++k) {
+        const double nv = vx[0] + (vx[1] - vx[0]) * 0.5;
+        const double fk = eval(start_shrink ? nv : xc);
+        if (start_shrink) {
+          ++evals;
+#pragma unroll
+          for (int q = 1; q < 4; ++q) {
+            c[q] = c[q + 1];
+            vx[q] = vx[q + 1];
+          }
+          c[4] = fk;
+          vx[4] = nv;
+        }
+      }
+      if (start_shrink) {
+        sort5(c, vx);
+        begin_iteration(true);
+      }
+    }
+    // ---- finished fits: results in fit order, then the next chain from the queue
+    if (__ballot(st == ST_DONE) != 0ull) {
+      const bool fin = st == ST_DONE;
+      const double b0 = dpp_mov<kDppQuadBcast0>(bx), b1 = dpp_mov<kDppQuadBcast1>(bx);
+      unsigned nxt = 0xffffffffu;
+      if (fin) {
+        if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
+        if (gl == 0) {
+          FitInfoDev fo;
+          fo.best_cost = best_cost;
+          fo.iters = iter;
+          fo.evals = evals;
+          fo.status = fin_status;
+          fo.lanes = G;  // reduction-tree code (oracle: `lanes`)
+          a.info[chain] = fo;
+          nxt = gridDim.x * NG + atomicAdd(a.queue, 1u);
+        }
+        if (a.raw) {
+          double* ro = a.raw + (size_t)chain * 7;
+          if (gl < 4) ro[gl] = bx;
+          if (gl == 4) ro[4] = est_mm(b0, b1);
+          if (gl == 5) ro[5] = est_um(b0, b1);
+          if (gl == 6) ro[6] = p_uu_est(b0, b1);
+        }
+      }
+      nxt = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (g * G), (int)nxt);  // the group leader's draw
+      if (fin) {
+        st = ST_IDLE;
+        if (nxt < total) {
+          chain = nxt;
+          setup_chain();
+        }
+      }
+      __syncthreads();
     }
   }
 }

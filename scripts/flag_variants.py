@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development aid (GPU box): build libabneutral_hip.so with extra compiler flags and run bench.py on each
 build (ABNEUTRAL_HIP_LIB points the package at the variant).  Usage:
-  python scripts/flag_variants.py [--workload c3] -- "" "-mllvm -amdgpu-sched-strategy=max-ilp" ..."""
+  python scripts/flag_variants.py [--workload c3] [--bench-args "--lanes 8"] -- "" "-mllvm -amdgpu-sched-strategy=max-ilp" ..."""
 import json, os, subprocess, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -11,6 +11,10 @@ args = sys.argv[1:]
 workloads = ["c3"]
 if args and args[0] == "--workload":
     workloads = args[1].split(",")
+    args = args[2:]
+bench_args = []
+if args and args[0] == "--bench-args":
+    bench_args = args[1].split()
     args = args[2:]
 if args and args[0] == "--":
     args = args[1:]
@@ -25,7 +29,7 @@ for i, flags in enumerate(args or [""]):
     for w in workloads:
         env = dict(os.environ, ABNEUTRAL_HIP_LIB=str(lib))
         r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--workload", w, "--no-stream-probe",
-                            "--no-cpu-baseline"], capture_output=True, text=True, env=env)
+                            "--no-cpu-baseline", *bench_args], capture_output=True, text=True, env=env)
         try:
             d = json.loads(r.stdout.strip().splitlines()[-1])
             print(f"[{flags}] {w}: {d['value']:.0f} fits/s, {d['ms_per_step']:.3f} ms/step, "

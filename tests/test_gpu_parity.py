@@ -656,6 +656,43 @@ def test_speculative_phase_a_all_branches(abn, gpu_ctx, golden, oracle, variant,
             assert out["best_start"][w] == k and np.array_equal(out["models"][w], model)
 
 
+@pytest.mark.parametrize("case", ("generated", "sparse"))
+def test_persistent_refill_kernel_is_schedule_independent(abn, gpu_ctx, golden, oracle, case):
+    """More wavefronts than the GPU holds (> 3072) and several chains per wavefront: phase B runs on the persistent
+    kernel whose lane groups take the next chain from an atomic queue.  Which group runs which chain depends
+    on timing; the results must not: byte-identical to the static launch (two window groups use the plain
+    kernel) and to the oracle."""
+    if case == "generated":      # N = 6 -> 8 lanes per chain, 8 chains per wavefront
+        ped, p0, W, S, B = golden["generated"], golden["p0uu_generated"], 13, 4, 2000
+    else:                        # N = 78 -> 16 lanes per chain, 4 chains per wavefront
+        ped, p0, W, S, B = golden["sparse"], golden["r_p0uu"], 8, 4, 1600
+    seed = 404
+    rng = np.random.default_rng(5)
+    D = np.abs(ped[:, 3][None, :] * rng.uniform(0.8, 1.25, (W, 1)))
+    p0w = np.clip(p0 * rng.uniform(0.9, 1.1, W), 0.05, 0.95)
+    outs = []
+    for groups in (1, 2):
+        plan = abn.Plan(gpu_ctx, ped[:, :3], W, S, B, options=abn.default_options(seed=seed, window_groups=groups))
+        plan.set_windows(D, p0w)
+        plan.run()
+        outs.append(plan.download())
+        plan.close()
+    lanes = int(outs[0]["info_b"]["lanes"][0, 0])
+    assert W * B // (64 // lanes) > 3072                  # the persistent launch was taken
+    for k in ("models", "pred", "resid", "raw", "best_start"):
+        assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
+    for k in ("info_a", "info_b"):
+        assert outs[0][k].tobytes() == outs[1][k].tobytes(), k
+    out = outs[0]
+    for w in (0, W - 1):
+        pw = np.concatenate([ped[:, :3], D[w][:, None]], axis=1)
+        raw, res = oracle.boot_model(pw, out["models"][w], out["pred"][w], out["resid"][w], p0w[w], p0w[w], 1.0,
+                                     seed, w, 0, B, lanes=lanes)
+        assert np.array_equal(out["raw"][w], raw, equal_nan=True)
+        for k in ("iters", "evals", "status"):
+            assert np.array_equal(out["info_b"][w][k], res[k]), k
+
+
 def test_reference_unit_tests_through_the_cpp_mirror(abn, gpu_ctx):
     """The reference's enabled unit tests on the path (same_as_r, test_cost_function, build_pedigree) restated
     against the C++ mirror of its API and executed on the GPU (alphabeta_rs_amd/host/reference_tests.cpp).
