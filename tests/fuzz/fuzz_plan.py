@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised plan-level parity sweep (development aid): phase A (speculative / two-pass / plain), selection,
-phase B (resident / stream) against per-window oracle runs."""
+"""Randomised plan-level parity sweep (development aid): phase A (speculative / two-pass / plain / persistent),
+selection, phase B (resident / stream / persistent) against per-window oracle runs."""
 import sys, time
 from pathlib import Path
 import numpy as np
@@ -21,6 +21,11 @@ def main(seconds=180, seed=0):
         W = int(rng.choice([1, 2, 5, 60]))
         S = int(rng.choice([1, 3, 10, 90])) if W < 60 else 90       # 60 x 90 > 4096 -> two-pass phase A
         B = int(rng.choice([1, 4, 16]))
+        big = n <= 200 and rng.random() < 0.15        # > 3072 wavefronts: the persistent (queue) kernel
+        if big:
+            W, B = int(rng.choice([3, 7])), int(rng.choice([2000, 5000]))
+            S = int(rng.choice([3, 10]))
+        skip_off = int(rng.random() < 0.2)
         mi_a, mi_b = int(rng.choice([1500, 3000])), int(rng.choice([100, 400]))
         variant = int(rng.integers(0, 2))
         seed_o = int(rng.integers(1, 1 << 30))
@@ -28,7 +33,7 @@ def main(seconds=180, seed=0):
         p0 = rng.uniform(0.55, 0.95, W)
         woff, boff = int(rng.integers(0, 1000)), int(rng.integers(0, 5000))
         o = A.default_options(seed=seed_o, shrink_on_failed_contraction=variant, max_iters_start=mi_a, max_iters_boot=mi_b,
-                              stream_mode=int(rng.integers(0, 2)))
+                              stream_mode=int(rng.integers(0, 2)), no_fixed_point_skip=skip_off)
         plan = A.Plan(ctx, ped[:, :3], W, S, B, window_offset=woff, boot_offset=boff, options=o)
         plan.set_windows(D, p0)
         plan.run()
