@@ -286,6 +286,20 @@ static abn_options resolve(const abn_options* o) {
   return d;
 }
 
+// iteration budgets must leave room for the 32-bit evaluation counters (at most 2 evaluations per iteration plus the
+// 4 of a shrink); lane counts are 0 (auto) or a power of two up to the wavefront; the tolerance must compare
+static const char* options_error(const abn_options& o) {
+  if (o.max_iters_start < 0 || o.max_iters_start > (1 << 28) || o.max_iters_boot < 0 || o.max_iters_boot > (1 << 28))
+    return "max_iters_start / max_iters_boot must be in 0 .. 2^28";
+  if (!(o.lanes_per_chain == 0 || o.lanes_per_chain == 8 || o.lanes_per_chain == 16 || o.lanes_per_chain == 32 ||
+        o.lanes_per_chain == 64))
+    return "lanes_per_chain must be 0 (auto), 8, 16, 32 or 64";
+  if (o.sd_tolerance != o.sd_tolerance) return "sd_tolerance is NaN";
+  if (o.stream_mode < 0 || o.stream_mode > 1) return "stream_mode must be 0 or 1";
+  if (o.window_groups < 0) return "window_groups must be >= 0";
+  return nullptr;
+}
+
 extern "C" int abn_version(void) { return ABN_VERSION_MAJOR * 100 + ABN_VERSION_MINOR; }
 
 extern "C" int abn_device_count(int* count) {
@@ -524,6 +538,8 @@ extern "C" int abn_fit_batch(abn_ctx* c, const abn_options* opts, const double* 
     return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
   if (f == 0) return ABN_OK;
   const abn_options o = resolve(opts);
+  if (const char* oe = options_error(o)) return set_err(c, ABN_ERR_INVALID_ARG, oe);
+  if (max_iters < 0 || max_iters > (1 << 28)) return set_err(c, ABN_ERR_INVALID_ARG, "max_iters must be in 0 .. 2^28");
   HIPCHK(c, hipSetDevice(c->device));
   Topology t;
   int rc = build_topology(pedigree, n_rows, 4, t);
@@ -645,6 +661,10 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
     return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
   if ((long long)n_windows * std::max(n_starts, n_boot) > 0x7fffffffLL)
     return set_err(c, ABN_ERR_INVALID_ARG, "too many chains");
+  {
+    const abn_options o = resolve(opts);
+    if (const char* oe = options_error(o)) return set_err(c, ABN_ERR_INVALID_ARG, oe);
+  }
   HIPCHK(c, hipSetDevice(c->device));
   abn_plan* p = new (std::nothrow) abn_plan();
   if (!p) return ABN_ERR_HIP;

@@ -446,6 +446,14 @@ def test_invalid_arguments_are_status_codes(abn, gpu_ctx, golden):
         plan.run()
     assert e.value.status == 6
     plan.close()
+    # options outside their range -> ABN_ERR_INVALID_ARG with a message
+    for bad in (dict(max_iters_start=-1), dict(max_iters_boot=1 << 29), dict(lanes_per_chain=12),
+                dict(sd_tolerance=float("nan")), dict(stream_mode=2)):
+        with pytest.raises(abn.AbnError) as e:
+            abn.Plan(gpu_ctx, ped[:, :3], 1, 2, 2, options=abn.default_options(**bad))
+        assert e.value.status == 1, bad
+    with pytest.raises(abn.AbnError):
+        gpu_ctx.fit_batch(ped, 0.7, 0.7, 1.0, np.zeros((1, 5, 4)), -5)
     # zero candidates / fits are fine
     assert gpu_ctx.cost_batch(ped, 0.7, 0.7, 1.0, np.zeros((0, 4))).shape == (0,)
 
