@@ -181,6 +181,9 @@ def main():
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "g351", "c5s", "mp"])
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--execute-stuck-fits", action="store_true",
+                    help="abn_options.no_fixed_point_skip = 1: execute the repeated iterations of fits that have reached "
+                         "argmin's fixed point, as the reference does (same outputs; default: finish them at once)")
     ap.add_argument("--no-stream-probe", action="store_true",
                     help="skip the short C5-shard run that measures the stream-mode kernel against the HBM roof")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -214,7 +217,8 @@ def main():
     N, Wr, S, B = wl["gens"].shape[0], wl["wr"], wl["S"], wl["B"]
     stream = torch.cuda.current_stream().cuda_stream
     ctx = A.Context(local_rank, stream=stream)
-    opts = A.default_options(seed=seed, lanes_per_chain=args.lanes)
+    opts = A.default_options(seed=seed, lanes_per_chain=args.lanes,
+                             no_fixed_point_skip=1 if args.execute_stuck_fits else 0)
     by_boot = wl.get("shard") == "bootstraps"
     plan = A.Plan(ctx, wl["gens"], Wr, S, B, window_offset=0 if by_boot else rank * Wr,
                   boot_offset=rank * B if by_boot else 0, options=opts)
@@ -342,6 +346,7 @@ def main():
             "candidate_evals_per_s": evals_per_s,
             "fits_per_step": tot_fits, "evals_per_step": tot_evals, "nm_iters_per_step": tot_iters,
             "evals_not_executed_per_step": tot_skipped,
+            "fixed_point_skip": not args.execute_stuck_fits,
             "kernel_ms": kms,
             "roofline": roofline,
         }
