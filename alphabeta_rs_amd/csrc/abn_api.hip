@@ -173,6 +173,7 @@ static hipError_t launch_fit_gt(const FitArgs& a, int rmax, dim3 grid, size_t ld
     case 2: hipLaunchKernelGGL((abn_fit_kernel<G, 2, TP>), grid, dim3(kWave), lds, s, a); break;
     case 4: hipLaunchKernelGGL((abn_fit_kernel<G, 4, TP>), grid, dim3(kWave), lds, s, a); break;
     case 8: hipLaunchKernelGGL((abn_fit_kernel<G, 8, TP>), grid, dim3(kWave), lds, s, a); break;
+    case -1: hipLaunchKernelGGL((abn_fit_kernel<G, -1, TP>), grid, dim3(kWave), lds, s, a); break;
     default: hipLaunchKernelGGL((abn_fit_kernel<G, 0, TP>), grid, dim3(kWave), lds, s, a); break;
   }
   return hipGetLastError();
@@ -205,6 +206,8 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
     if ((size_t)ng * (size_t)(a.chain_stride + np) * sizeof(double) > kLdsResidentMax) rmax = 0;
     else a.chain_stride += np;
   }
+  // stream mode: rows shorter than one trip of the deep loop (kStreamBlocks x 4 rows x lanes) use the pair-loop variant
+  if (rmax == 0 && a.N < 2 * kStreamBlocks * kStreamVec * lanes) rmax = -1;
   const size_t lds = (size_t)ng * (size_t)a.chain_stride * sizeof(double);
   if (lds > kMaxDynLds)
     return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS per workgroup than supported (T or K too large)");

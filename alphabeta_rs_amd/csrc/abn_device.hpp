@@ -16,6 +16,7 @@
 //   P4  per row: (D_i - c - dt[tid_i])^2 + penalty     src/structs.rs:208-213        (lane per row)
 //   P5  xor-butterfly over the G lanes                 (the oracle's `lanes=G` order)
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -381,8 +382,11 @@ __device__ __forceinline__ double group_sum_dpp(double v) {
 // ------------------------------------------------------------------------------------------------
 template <int G, int RMAX, bool TWOPASS = false>
 __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)) void abn_fit_kernel(const FitArgs a) {
+  // RMAX == 0: stream mode for long rows (deep loop, kStreamWaves wavefronts per SIMD); RMAX == -1: stream mode for
+  // mid-size pedigrees whose rows never fill the deep loop (pairs of blocks, three wavefronts per SIMD)
   constexpr int NG = kWave / G;
-  constexpr bool STREAM = (RMAX == 0);
+  constexpr bool STREAM = (RMAX <= 0);
+  constexpr int SNB = RMAX == 0 ? kStreamBlocks : 2;  // row blocks a lane keeps in flight in stream mode
   constexpr int RR = RMAX > 0 ? RMAX : 1;
   extern __shared__ __align__(16) double lds[];
 
@@ -513,61 +517,66 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
       // in flight per iteration, the dependent residual gathers issued together.  The per-lane accumulation
       // order (block by block, row by row) is what the oracle's lanes code `G | 3 << 8` reproduces.
       constexpr int V = kStreamVec;
-      constexpr int NB = kStreamBlocks;                              // full blocks in flight per lane
       const int stride = V * G;
       int base = V * gl;
-      for (; base + (NB - 1) * stride + V <= N; base += NB * stride) {
-        double d[NB * V], t[NB * V];
-        u16x4 tq[NB];
+      // NBK full blocks of this lane in flight; consumed block by block, row by row
+      auto blocks = [&](auto nbk) {
+        constexpr int NB = decltype(nbk)::value;
+        for (; base + (NB - 1) * stride + V <= N; base += NB * stride) {
+          double d[NB * V], t[NB * V];
+          u16x4 tq[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) tq[b] = *reinterpret_cast<const u16x4*>(a.tid + base + b * stride);
-        if (a.dmode == 1) {
-          u32x4 ix[NB];
-          f64x2 pl[NB], ph[NB];
+          for (int b = 0; b < NB; ++b) tq[b] = *reinterpret_cast<const u16x4*>(a.tid + base + b * stride);
+          if (a.dmode == 1) {
+            u32x4 ix[NB];
+            f64x2 pl[NB], ph[NB];
 #pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            ix[b] = *reinterpret_cast<const u32x4*>(idx_row + base + b * stride);
-            pl[b] = *reinterpret_cast<const f64x2*>(a.pred + wN + base + b * stride);
-            ph[b] = *reinterpret_cast<const f64x2*>(a.pred + wN + base + b * stride + 2);
+            for (int b = 0; b < NB; ++b) {
+              ix[b] = *reinterpret_cast<const u32x4*>(idx_row + base + b * stride);
+              pl[b] = *reinterpret_cast<const f64x2*>(a.pred + wN + base + b * stride);
+              ph[b] = *reinterpret_cast<const f64x2*>(a.pred + wN + base + b * stride + 2);
+            }
+            const double* rs = a.resid + wN;
+            double rg[NB * V];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+              for (int e = 0; e < V; ++e) rg[b * V + e] = rs[ix[b][e]];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {                             // src/boot_model.rs:50-54
+              d[b * V + 0] = pl[b][0] + rg[b * V + 0];
+              d[b * V + 1] = pl[b][1] + rg[b * V + 1];
+              d[b * V + 2] = ph[b][0] + rg[b * V + 2];
+              d[b * V + 3] = ph[b][1] + rg[b * V + 3];
+            }
+          } else {
+            f64x2 ql[NB], qh[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              ql[b] = *reinterpret_cast<const f64x2*>(a.D + dN + base + b * stride);
+              qh[b] = *reinterpret_cast<const f64x2*>(a.D + dN + base + b * stride + 2);
+            }
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              d[b * V + 0] = ql[b][0];
+              d[b * V + 1] = ql[b][1];
+              d[b * V + 2] = qh[b][0];
+              d[b * V + 3] = qh[b][1];
+            }
           }
-          const double* rs = a.resid + wN;
-          double rg[NB * V];
 #pragma unroll
           for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int e = 0; e < V; ++e) rg[b * V + e] = rs[ix[b][e]];
+            for (int e = 0; e < V; ++e) t[b * V + e] = dtab[tq[b][e]];
 #pragma unroll
-          for (int b = 0; b < NB; ++b) {                             // src/boot_model.rs:50-54
-            d[b * V + 0] = pl[b][0] + rg[b * V + 0];
-            d[b * V + 1] = pl[b][1] + rg[b * V + 1];
-            d[b * V + 2] = ph[b][0] + rg[b * V + 2];
-            d[b * V + 3] = ph[b][1] + rg[b * V + 3];
-          }
-        } else {
-          f64x2 ql[NB], qh[NB];
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            ql[b] = *reinterpret_cast<const f64x2*>(a.D + dN + base + b * stride);
-            qh[b] = *reinterpret_cast<const f64x2*>(a.D + dN + base + b * stride + 2);
-          }
-#pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            d[b * V + 0] = ql[b][0];
-            d[b * V + 1] = ql[b][1];
-            d[b * V + 2] = qh[b][0];
-            d[b * V + 3] = qh[b][1];
+          for (int e = 0; e < NB * V; ++e) {
+            const double r = d[e] - ic - t[e];
+            acc = acc + (r * r + pen);
           }
         }
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-          for (int e = 0; e < V; ++e) t[b * V + e] = dtab[tq[b][e]];
-#pragma unroll
-        for (int e = 0; e < NB * V; ++e) {
-          const double r = d[e] - ic - t[e];
-          acc = acc + (r * r + pen);
-        }
-      }
+      };
+      blocks(std::integral_constant<int, SNB>{});                    // deep loop for long rows (HBM latency) ...
+      if (SNB > 2) blocks(std::integral_constant<int, 2>{});          // ... then pairs for what is left
       for (; base < N; base += stride) {                             // remaining (possibly partial) blocks
 #pragma unroll
         for (int e = 0; e < V; ++e) {
