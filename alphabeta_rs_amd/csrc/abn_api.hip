@@ -163,6 +163,9 @@ static int pick_rmax(int n, int lanes) {
   if (per <= 2) return 2;
   if (per <= 4) return 4;
   if (per <= 8) return 8;
+  // 512 < N <= 1024: still LDS-resident with one wavefront per chain (scripts/n_sweep.py, N = 820, 2000 bootstraps:
+  // 5.25 -> 4.0 ms; 32 rows per lane with the triple ids in LDS gained nothing over streaming: not kept)
+  if (per <= 16 && lanes == 64) return 16;
   return 0;  // stream mode
 }
 
@@ -173,6 +176,9 @@ static hipError_t launch_fit_gt(const FitArgs& a, int rmax, dim3 grid, size_t ld
     case 2: hipLaunchKernelGGL((abn_fit_kernel<G, 2, TP>), grid, dim3(kWave), lds, s, a); break;
     case 4: hipLaunchKernelGGL((abn_fit_kernel<G, 4, TP>), grid, dim3(kWave), lds, s, a); break;
     case 8: hipLaunchKernelGGL((abn_fit_kernel<G, 8, TP>), grid, dim3(kWave), lds, s, a); break;
+    case 16:  // one wavefront per chain only (pick_rmax)
+      hipLaunchKernelGGL((abn_fit_kernel<64, 16, TP>), grid, dim3(kWave), lds, s, a);
+      break;
     case -1: hipLaunchKernelGGL((abn_fit_kernel<G, -1, TP>), grid, dim3(kWave), lds, s, a); break;
     default: hipLaunchKernelGGL((abn_fit_kernel<G, 0, TP>), grid, dim3(kWave), lds, s, a); break;
   }
@@ -243,7 +249,7 @@ static bool fit_streams(int n, int chain_stride, int lanes) {
 static bool spec_applicable(const FitArgs& a) {
   if (a.dmode != 0 || a.smode != 0) return false;
   const int rmax = pick_rmax(a.N, kWave);
-  if (rmax == 0) return false;
+  if (rmax == 0 || rmax > 8) return false;  // 16 rows per lane: the plain resident kernel
   const int np = (a.N + 1) & ~1;
   return (3 * (size_t)(a.chain_stride + np) + kSpecCommDoubles) * sizeof(double) <= kLdsResidentMax;
 }

@@ -497,18 +497,22 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
     ABN_STAMP(2);
     double acc = 0.0;                                        // P4
     if (!STREAM) {
-      double dv[RR], tv[RR];
+      constexpr int RC = RR < 8 ? RR : 8;                    // eight rows per lane at a time
 #pragma unroll
-      for (int q = 0; q < RR; ++q) {                         // all LDS reads first, then the arithmetic;
-        const int i = gl + G * q;                            // rows past the end read row N-1 and add +0.0
-        dv[q] = dobs[i < N ? i : N - 1];
-        tv[q] = dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu];
-      }
+      for (int q0 = 0; q0 < RR; q0 += RC) {
+        double dv[RC], tv[RC];
 #pragma unroll
-      for (int q = 0; q < RR; ++q) {
-        const double r = dv[q] - ic - tv[q];
-        const double term = r * r + pen;
-        acc = acc + (((gl + G * q) < N) ? term : 0.0);       // x + 0.0 == x bit for bit (acc is never -0.0)
+        for (int q = 0; q < RC; ++q) {                       // all LDS reads first, then the arithmetic;
+          const int i = gl + G * (q0 + q);                   // rows past the end read row N-1 and add +0.0
+          dv[q] = dobs[i < N ? i : N - 1];
+          tv[q] = dtab[(tidp[(q0 + q) / 2] >> (16 * ((q0 + q) & 1))) & 0xffffu];
+        }
+#pragma unroll
+        for (int q = 0; q < RC; ++q) {
+          const double r = dv[q] - ic - tv[q];
+          const double term = r * r + pen;
+          acc = acc + (((gl + G * (q0 + q)) < N) ? term : 0.0);  // x + 0.0 == x bit for bit (acc is never -0.0)
+        }
       }
     } else {
       // stream mode.  Lane l owns row blocks of kStreamVec = 4 consecutive rows: rows 4(l + G q) .. +3 for

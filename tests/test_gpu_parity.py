@@ -138,20 +138,23 @@ def test_fit_batch_trajectories_bit_exact(abn, gpu_ctx, golden, oracle, lanes, v
 
 
 def test_fit_batch_stream_mode_large_pedigree(abn, gpu_ctx, oracle):
-    """N > 8 rows per lane: the kernel re-streams rows every evaluation (stream mode)."""
+    """More rows than the LDS-resident variants hold (8 per lane; 16 per lane with one wavefront per chain):
+    the kernel re-streams rows every evaluation (stream mode).  N = 700 is streamed with 16 lanes per chain
+    and resident (16 rows per lane) with 64; N = 1100 is streamed either way."""
     rng = np.random.default_rng(77)
-    ped = synthetic_pedigree(rng, 700, 12)
     true = np.array([1e-4, 5e-4, 0.03, 1e-3])
-    dt, _ = oracle.divergence(ped, 0.25, 0.75, *true[:3], table=True)
-    ped[:, 3] = np.maximum(true[3] + dt + rng.normal(0, 2e-4, 700), 0)
-    s0 = abn.gen_start_simplices(5, 0, 6, ped[:, 3].max())
-    for lanes in (16, 64):
-        o = abn.default_options(lanes_per_chain=lanes)
-        best, info = gpu_ctx.fit_batch(ped, 0.75, 0.75, 1.0, s0, 300, options=o)
-        code = int(info["lanes"][0])          # stream mode: lanes | (rows per block - 1) << 8
-        assert code & 0xff == lanes and code >> 8 == 3
-        want = oracle.fit_batch(ped, 0.75, 0.75, 1.0, s0, 300, lanes=code)
-        _assert_fits_equal(best, info, want)
+    for n, expect in ((700, {16: 3, 64: 0}), (1100, {16: 3, 64: 3})):
+        ped = synthetic_pedigree(rng, n, 12)
+        dt, _ = oracle.divergence(ped, 0.25, 0.75, *true[:3], table=True)
+        ped[:, 3] = np.maximum(true[3] + dt + rng.normal(0, 2e-4, n), 0)
+        s0 = abn.gen_start_simplices(5, 0, 6, ped[:, 3].max())
+        for lanes in (16, 64):
+            o = abn.default_options(lanes_per_chain=lanes)
+            best, info = gpu_ctx.fit_batch(ped, 0.75, 0.75, 1.0, s0, 300, options=o)
+            code = int(info["lanes"][0])          # stream mode: lanes | (rows per block - 1) << 8
+            assert code & 0xff == lanes and code >> 8 == expect[lanes]
+            want = oracle.fit_batch(ped, 0.75, 0.75, 1.0, s0, 300, lanes=code)
+            _assert_fits_equal(best, info, want)
 
 
 def test_fit_batch_per_fit_observations(abn, gpu_ctx, golden, oracle):
