@@ -10,12 +10,14 @@ import alphabeta_rs_amd as A
 from alphabeta_rs_amd import synthetic
 
 ctx = A.Context(0)
-B = 2000
-for nl in (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20):
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+LANES = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+NLS = [int(x) for x in sys.argv[3].split(',')] if len(sys.argv) > 3 else (1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20)
+for nl in NLS:
     ped, p0 = synthetic.c5_pedigree(nl, 30, 3)
     N = ped.shape[0]
     K = len({tuple(r) for r in ped[:, :3].astype(int).tolist()})
-    plan = A.Plan(ctx, ped[:, :3], 1, 4, B, options=A.default_options())
+    plan = A.Plan(ctx, ped[:, :3], 1, 4, B, options=A.default_options(lanes_per_chain=LANES))
     plan.set_windows(ped[:, 3][None, :], np.array([p0]))
     plan.run(); plan.run()
     ms = plan.kernel_ms()
