@@ -898,6 +898,7 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   s.best_start = p->best_start.p + o;
   const size_t lds = ((size_t)9 * a.TP + p->topo.KP + kSelChunk) * sizeof(double);
   if (timed) HIPCHK(c, hipEventRecord(p->ev[2], st));
+  hipLaunchKernelGGL(abn_select_lse_kernel, dim3((unsigned)((long long)wn * p->S)), dim3(kWave), lds, st, s);
   hipLaunchKernelGGL(abn_select_kernel, dim3((unsigned)wn), dim3(kWave), lds, st, s);
   HIPCHK(c, hipGetLastError());
   if (timed) HIPCHK(c, hipEventRecord(p->ev[3], st));
@@ -1270,6 +1271,7 @@ extern "C" int abn_select_best(abn_ctx* c, const double* pedigree, int32_t n_row
   a.pred = dpred.p;
   a.resid = dresid.p;
   a.best_start = dbest.p;
+  hipLaunchKernelGGL(abn_select_lse_kernel, dim3((unsigned)a.S), dim3(kWave), lds, c->stream, a);
   hipLaunchKernelGGL(abn_select_kernel, dim3(1), dim3(kWave), lds, c->stream, a);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(best_index, dbest.p, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));

@@ -1489,7 +1489,7 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
 }
 
 // ------------------------------------------------------------------------------------------------
-// Selection kernel: src/ab_neutral.rs:83-135.  One wavefront per window.  The pure LSE of each of the
+// Selection kernels: src/ab_neutral.rs:83-135.  The pure LSE of each of the
 // S fitted models is summed SERIALLY in row order (the reference's `.sum::<f64>()`), the stable
 // arg-min taken (lowest start index on ties; NaN never wins), then predicted divergence and residuals
 // of the winner written for phase B.  LDS: chain scratch (9*TP + K doubles) + kSelChunk terms.
@@ -1512,45 +1512,61 @@ struct SelectArgs {
   int32_t* best_start;  // [W]  (-1: no finite fit)
 };
 
+// P1-P3 of one model for the whole wavefront: power table and dt[K] into LDS
+__device__ __forceinline__ void select_fill_dt(const SelectArgs& a, const double* x, double p_uu0, double* pw,
+                                               double* dtab, int lane) {
+  const double p_mm = 1.0 - p_uu0;
+  const Gen Gm = genmatrix(x[0], x[1]);
+  const double sv0 = p_uu0, sv1 = x[2] * p_mm, sv2 = (1.0 - x[2]) * p_mm;
+  build_power_table<kWave>(Gm, a.T, a.TP, pw, lane);
+  __syncthreads();
+  for (int t = lane; t < a.K; t += kWave) dtab[t] = triple_dt(a.tri[t], pw, a.TP, sv0, sv1, sv2);
+  __syncthreads();
+}
+
+// Step 1: one wavefront per (window, start) — the pure LSE of that fitted model, summed serially in row order
+__global__ __launch_bounds__(kWave) void abn_select_lse_kernel(const SelectArgs a) {
+  extern __shared__ __align__(16) double lds[];
+  const int lane = threadIdx.x;
+  const int w = blockIdx.x / a.S, sidx = blockIdx.x - w * a.S;
+  const int N = a.N;
+  double* pw = lds;
+  double* dtab = pw + 9 * a.TP;
+  double* term = dtab + ((a.K + 1) & ~1);
+  const size_t wN = (size_t)w * (size_t)N;
+  double x[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) x[d] = a.models[((size_t)w * a.S + sidx) * 4 + d];
+  select_fill_dt(a, x, a.p_uu[w], pw, dtab, lane);
+  double lsum = 0.0;
+  for (int base = 0; base < N; base += kSelChunk) {
+    const int cnt = (N - base) < kSelChunk ? (N - base) : kSelChunk;
+    for (int i = lane; i < cnt; i += kWave) {
+      const double r = a.D[wN + base + i] - x[3] - dtab[a.tid[base + i]];
+      term[i] = r * r;
+    }
+    __syncthreads();
+    for (int i = 0; i < cnt; ++i) lsum = lsum + term[i];
+    __syncthreads();
+  }
+  if (lane == 0) a.lse[(size_t)w * a.S + sidx] = lsum;
+}
+
+// Step 2: one wavefront per window — stable arg-min over the starts (lowest index on ties; NaN and non-finite
+// fits never win), predicted divergence and residuals of the winner
 __global__ __launch_bounds__(kWave) void abn_select_kernel(const SelectArgs a) {
   extern __shared__ __align__(16) double lds[];
   const int lane = threadIdx.x;
   const int w = blockIdx.x;
-  const int N = a.N, K = a.K, TP = a.TP;
+  const int N = a.N;
   double* pw = lds;
-  double* dtab = pw + 9 * TP;
-  double* term = dtab + ((K + 1) & ~1);
-  const double p_uu0 = a.p_uu[w], p_mm = 1.0 - p_uu0;
+  double* dtab = pw + 9 * a.TP;
   const size_t wN = (size_t)w * (size_t)N;
-
-  auto fill_dt = [&](const double* x) {
-    const Gen Gm = genmatrix(x[0], x[1]);
-    const double sv0 = p_uu0, sv1 = x[2] * p_mm, sv2 = (1.0 - x[2]) * p_mm;
-    build_power_table<kWave>(Gm, a.T, TP, pw, lane);
-    __syncthreads();
-    for (int t = lane; t < K; t += kWave) dtab[t] = triple_dt(a.tri[t], pw, TP, sv0, sv1, sv2);
-    __syncthreads();
-  };
 
   int best = -1;
   double best_lse = __builtin_inf();
   for (int sidx = 0; sidx < a.S; ++sidx) {
-    double x[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d) x[d] = a.models[((size_t)w * a.S + sidx) * 4 + d];
-    fill_dt(x);
-    double lsum = 0.0;
-    for (int base = 0; base < N; base += kSelChunk) {
-      const int cnt = (N - base) < kSelChunk ? (N - base) : kSelChunk;
-      for (int i = lane; i < cnt; i += kWave) {
-        const double r = a.D[wN + base + i] - x[3] - dtab[a.tid[base + i]];
-        term[i] = r * r;
-      }
-      __syncthreads();
-      for (int i = 0; i < cnt; ++i) lsum = lsum + term[i];
-      __syncthreads();
-    }
-    if (lane == 0) a.lse[(size_t)w * a.S + sidx] = lsum;
+    const double lsum = a.lse[(size_t)w * a.S + sidx];
     const bool ok = (lsum == lsum) && (a.info[(size_t)w * a.S + sidx].status != 2);
     if (ok && (best < 0 || lsum < best_lse)) {
       best = sidx;
@@ -1569,7 +1585,7 @@ __global__ __launch_bounds__(kWave) void abn_select_kernel(const SelectArgs a) {
   double x[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d) x[d] = a.models[((size_t)w * a.S + best) * 4 + d];
-  fill_dt(x);
+  select_fill_dt(a, x, a.p_uu[w], pw, dtab, lane);
   for (int i = lane; i < N; i += kWave) {
     const double p = x[3] + dtab[a.tid[i]];      // src/ab_neutral.rs:123-129
     a.pred[wN + i] = p;
