@@ -352,7 +352,7 @@ def main():
         }
         if world == 1 and not args.no_stream_probe and args.workload != "c5s":
             result["roofline_stream"] = stream_probe(A, ctx, seed)
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a one-GPU (rank 0) measurement
             bs = int(out["best_start"][0])
             if bs >= 0:
                 result["cpu_baseline"] = cpu_baseline(wl, out["models"][0], out["pred"][0], out["resid"][0], lanes, seed,
