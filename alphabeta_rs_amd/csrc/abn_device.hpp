@@ -886,7 +886,7 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
       wconst[2] = a.eqp[wi];
       wconst[3] = a.eqp_w[wi] * (double)N;              // eqp_weight * nrows, src/structs.rs:210-211
     }
-    const uint32_t* idx_row = a.idx + (size_t)chain * (size_t)N;
+    const uint32_t* idx_row = (a.dmode == 1) ? a.idx + (size_t)chain * (size_t)N : nullptr;
     const size_t dN = (a.dmode == 2) ? (size_t)chain * (size_t)N : wN;
 #pragma unroll
     for (int q = 0; q < RR; ++q) {
@@ -923,7 +923,8 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
   if (chain < total) setup_chain();
   __syncthreads();
 
-  // ---- one cost evaluation (as abn_fit_kernel, resident mode)
+  // ---- one cost evaluation: the resident branch of abn_fit_kernel's, statement for statement (keep the two in
+  // step; tests/test_gpu_parity.py::test_persistent_refill_kernel_is_schedule_independent compares their outputs)
   auto eval = [&](double xd) -> double {
     const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
     const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
