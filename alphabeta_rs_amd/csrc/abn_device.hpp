@@ -213,9 +213,9 @@ __device__ __forceinline__ void build_power_table(Gen Gm, int T, int TP, double*
   asm("" : "+v"(Gm.g3), "+v"(Gm.g4), "+v"(Gm.g5));
   asm("" : "+v"(Gm.g6), "+v"(Gm.g7), "+v"(Gm.g8));
   if (G == 16 || G == 32) {
-    if (gl < 12) {  // quads 0..2 of the group; lane position 3 of each quad mirrors position 2 and never stores
+    if (gl < 12) {  // quads 0..2 of the group; lane position 3 of each quad mirrors position 2
       const int i = gl >> 2, jr = gl & 3;
-      const bool j1 = (jr == 1), j2 = (jr >= 2), st = (jr < 3);
+      const bool j1 = (jr == 1), j2 = (jr >= 2);  // position 3 computes and stores what position 2 does (same address)
       const bool i1 = (i == 1), i2 = (i == 2);
       const double gc0 = j2 ? Gm.g2 : (j1 ? Gm.g1 : Gm.g0);  // column j of G
       const double gc1 = j2 ? Gm.g5 : (j1 ? Gm.g4 : Gm.g3);
@@ -223,16 +223,17 @@ __device__ __forceinline__ void build_power_table(Gen Gm, int T, int TP, double*
       const int j = j2 ? 2 : jr;
       double* pe = pw + 3 * i + j;
       double r = (i == j) ? 1.0 : 0.0;                        // identity, :21-24
-      if (st) pe[0] = r;
+      pe[0] = r;
       if (T >= 1) {
         r = i2 ? gc2 : (i1 ? gc1 : gc0);                      // matrix.clone(), :25  (G[i][j])
-        if (st) pe[9] = r;
+        pe[9] = r;
         double* pk = pe + 18;
+#pragma unroll 2
         for (int k = 2; k <= T; ++k) {                        // :27-29
           const double b0 = dpp_mov<kDppQuadBcast0>(r), b1 = dpp_mov<kDppQuadBcast1>(r);
           const double b2 = dpp_mov<kDppQuadBcast2>(r);
           r = fma3(b2, gc2, fma3(b1, gc1, fma3(b0, gc0, 0.0)));
-          if (st) pk[0] = r;
+          pk[0] = r;
           pk += 9;
         }
       }
@@ -484,12 +485,19 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
     const double dq = puu - wconst[2];
     const double pen = wconst[3] * (dq * dq);                // src/structs.rs:210-212
     ABN_STAMP(0);
+    // this lane's first triple is fetched before the power table is built and every later one a round ahead:
+    // the LDS latency of the triple list stays off the path
+    uint32_t tr = STREAM ? 0u : tri_s[gl < K ? gl : 0];
     build_power_table<G>(Gm, a.T, TP, pw, gl);               // P2
     __syncthreads();
     ABN_STAMP(1);
     if (!STREAM) {                                           // P3: ceil(K/G) rounds, one triple per lane
 #pragma unroll 1
-      for (int t = gl; t < K; t += G) dtab[t] = triple_dt(tri_s[t], pw, TP, sv0, sv1, sv2);
+      for (int t = gl; t < K; t += G) {
+        const uint32_t trn = tri_s[t + G < K ? t + G : 0];
+        dtab[t] = triple_dt(tr, pw, TP, sv0, sv1, sv2);
+        tr = trn;
+      }
     } else {
       for (int t = gl; t < K; t += G) dtab[t] = triple_dt(a.tri[t], pw, TP, sv0, sv1, sv2);
     }
@@ -934,10 +942,15 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
     const double puu = p_uu_est(al, be);                     // src/divergence.rs:92
     const double dq = puu - wconst[2];
     const double pen = wconst[3] * (dq * dq);                // src/structs.rs:210-212
+    uint32_t tr = tri_s[gl < K ? gl : 0];                    // first triple early, later ones a round ahead
     build_power_table<G>(Gm, a.T, TP, pw, gl);               // P2
     __syncthreads();
 #pragma unroll 1
-    for (int t = gl; t < K; t += G) dtab[t] = triple_dt(tri_s[t], pw, TP, sv0, sv1, sv2);  // P3
+    for (int t = gl; t < K; t += G) {                        // P3
+      const uint32_t trn = tri_s[t + G < K ? t + G : 0];
+      dtab[t] = triple_dt(tr, pw, TP, sv0, sv1, sv2);
+      tr = trn;
+    }
     __syncthreads();
     double acc = 0.0;                                        // P4
     constexpr int RC = RR < 8 ? RR : 8;
