@@ -487,7 +487,7 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
     ABN_STAMP(0);
     // this lane's first triple is fetched before the power table is built and every later one a round ahead:
     // the LDS latency of the triple list stays off the path
-    uint32_t tr = STREAM ? 0u : tri_s[gl < K ? gl : 0];
+    uint32_t tr = STREAM ? a.tri[gl < K ? gl : 0] : tri_s[gl < K ? gl : 0];
     build_power_table<G>(Gm, a.T, TP, pw, gl);               // P2
     __syncthreads();
     ABN_STAMP(1);
@@ -499,7 +499,12 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
         tr = trn;
       }
     } else {
-      for (int t = gl; t < K; t += G) dtab[t] = triple_dt(a.tri[t], pw, TP, sv0, sv1, sv2);
+#pragma unroll 1
+      for (int t = gl; t < K; t += G) {
+        const uint32_t trn = a.tri[t + G < K ? t + G : 0];
+        dtab[t] = triple_dt(tr, pw, TP, sv0, sv1, sv2);
+        tr = trn;
+      }
     }
     __syncthreads();
     ABN_STAMP(2);
