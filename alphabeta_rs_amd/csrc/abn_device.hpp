@@ -212,7 +212,7 @@ __device__ __forceinline__ void build_power_table(Gen Gm, int T, int TP, double*
   asm("" : "+v"(Gm.g0), "+v"(Gm.g1), "+v"(Gm.g2));
   asm("" : "+v"(Gm.g3), "+v"(Gm.g4), "+v"(Gm.g5));
   asm("" : "+v"(Gm.g6), "+v"(Gm.g7), "+v"(Gm.g8));
-  if (G == 16 || G == 32) {
+  if constexpr (G == 16 || G == 32) {
     if (gl < 12) {  // quads 0..2 of the group; lane position 3 of each quad mirrors position 2
       const int i = gl >> 2, jr = gl & 3;
       const bool j1 = (jr == 1), j2 = (jr >= 2);  // position 3 computes and stores what position 2 does (same address)
@@ -228,10 +228,9 @@ __device__ __forceinline__ void build_power_table(Gen Gm, int T, int TP, double*
         r = i2 ? gc2 : (i1 ? gc1 : gc0);                      // matrix.clone(), :25  (G[i][j])
         pe[9] = r;
         double* pk = pe + 18;
-#pragma unroll 2
-        for (int k = 2; k <= T; ++k) {                        // :27-29
-          const double b0 = dpp_mov<kDppQuadBcast0>(r), b1 = dpp_mov<kDppQuadBcast1>(r);
-          const double b2 = dpp_mov<kDppQuadBcast2>(r);
+        for (int k = 2; k <= T; ++k) {                        // :27-29 (hipcc does not unroll a loop of DPP
+          const double b0 = dpp_mov<kDppQuadBcast0>(r), b1 = dpp_mov<kDppQuadBcast1>(r);  // operations with a run-time
+          const double b2 = dpp_mov<kDppQuadBcast2>(r);                                     // trip count; by hand: no gain)
           r = fma3(b2, gc2, fma3(b1, gc1, fma3(b0, gc0, 0.0)));
           pk[0] = r;
           pk += 9;
