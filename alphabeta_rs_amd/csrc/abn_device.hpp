@@ -269,6 +269,84 @@ __device__ __forceinline__ void build_power_table(Gen Gm, int T, int TP, double*
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// P2 on the f64 matrix instruction.  v_mfma_f64_4x4x4 multiplies four independent 4x4 blocks; its dot products
+// are the k-ASCENDING chain of fused multiply-adds, rounded after every step — bit for bit the reference's
+// `result.dot(matrix)` (scripts/mfma_f64_probe.hip: 1.28 M random elements, 3x3 blocks padded with zeros, NaN /
+// infinities / denormals / overflow: no mismatch against fma(a2,b2, fma(a1,b1, fma(a0,b0, 0)))).  This is not a
+// reshaping of the path into a GEMM: the 3x3 transition-matrix product IS the operation, the instruction is used
+// as a four-chains-wide FMA chain.
+//   layout (read off the probe): A[blk][i][k] at lane i + 4 blk + 16 k, B[blk][k][j] at lane j + 4 blk + 16 k,
+//   D[blk][i][j] at lane j + 4 blk + 16 i.
+// With A = G^T (constant) and B = (G^n)^T the result D = G^T (G^n)^T = (G^n G)^T has B's layout again, so the
+// whole chain is one dependent MFMA per power (48 cycles, measured) with no data movement in between; block blk
+// works for chain blk of the wavefront (64/G chains; G = 8: two instructions per power).  Lane (x = lane & 3,
+// y = lane >> 4) of block blk holds element [x][y] of chain blk's running power and stores it to that chain's
+// table pw[n][3 x + y].  All 64 lanes must be active (MFMA ignores EXEC).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lane_fetch(double v, int src_lane) {  // ds_bpermute: v of lane src_lane
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// Build switch: -DABN_NO_MATRIX_FMA compiles the VALU form (build_power_table) instead — same bits, for A/B timing.
+#ifdef ABN_NO_MATRIX_FMA
+constexpr bool kMatrixFma = false;
+#else
+constexpr bool kMatrixFma = true;
+#endif
+
+template <int G>
+__device__ __forceinline__ void build_power_table_mx(double al, double be, int T, double* lds0, int chain_stride,
+                                                     double* dump, int lane) {
+  constexpr int NG = kWave / G;               // chains of this wavefront
+  constexpr int NH = NG > 4 ? 2 : 1;          // matrix instructions per product (four chains each)
+  const int x = lane & 3, blk = (lane >> 2) & 3, y = lane >> 4;
+  double A[NH], B[NH];
+  double* dst[NH];
+  int step[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const int c = blk + 4 * h;                // the chain this lane's block works for
+    double ac = al, bc = be;
+    if (NG > 1) {                             // its candidate: any lane of group c holds (alpha, beta)
+      const int src = (c < NG ? c : 0) * G;
+      ac = lane_fetch(al, src);
+      bc = lane_fetch(be, src);
+    }
+    Gen Gc = genmatrix(ac, bc);
+    asm("" : "+v"(Gc.g0), "+v"(Gc.g1), "+v"(Gc.g2));
+    asm("" : "+v"(Gc.g3), "+v"(Gc.g4), "+v"(Gc.g5));
+    asm("" : "+v"(Gc.g6), "+v"(Gc.g7), "+v"(Gc.g8));
+    // A = G^T: element G[y][x]; zero outside 3x3
+    const double r0 = x == 0 ? Gc.g0 : (x == 1 ? Gc.g1 : Gc.g2);
+    const double r1 = x == 0 ? Gc.g3 : (x == 1 ? Gc.g4 : Gc.g5);
+    const double r2 = x == 0 ? Gc.g6 : (x == 1 ? Gc.g7 : Gc.g8);
+    const double gyx = y == 0 ? r0 : (y == 1 ? r1 : r2);
+    const bool in3 = (x < 3) && (y < 3);
+    A[h] = in3 ? gyx : 0.0;
+    // B = (G^1)^T: element G[x][y] = A of the lane with x and y exchanged (same block)
+    B[h] = lane_fetch(A[h], y + 4 * blk + 16 * x);
+    // lanes outside the 3x3 block (or of an unused block) store too — always to `dump`, a slot of the caller's that
+    // nobody reads before it is rewritten: no store predicate in the loop
+    const bool st = in3 && (c < NG);
+    dst[h] = st ? lds0 + (size_t)c * chain_stride + 3 * x + y : dump;
+    step[h] = st ? 9 : 0;
+    dst[h][0] = (x == y) ? 1.0 : 0.0;         // identity, :21-24
+    dst[h] += step[h];
+    if (T >= 1) dst[h][0] = B[h];             // matrix.clone(), :25
+  }
+  for (int n = 2; n <= T; ++n) {              // :27-29
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      B[h] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[h], B[h], 0.0, 0, 0, 0);
+      dst[h] += step[h];
+      dst[h][0] = B[h];
+    }
+  }
+}
+
 // conditional divergence of one start state, src/divergence.rs:68-87 (this exact association)
 __device__ __forceinline__ double cond_div(double a0, double a1, double a2, double b0, double b1, double b2) {
   return 0.5 * (a0 * b1 + a1 * b0 + a1 * b2 + a2 * b1) + (a0 * b2 + a2 * b0);
@@ -477,7 +555,6 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
     ABN_STAMP(6);  // Nelder-Mead bookkeeping since the previous evaluation
     const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
     const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
-    const Gen Gm = genmatrix(al, be);                        // P1
     const double p_mm = wconst[1];
     const double sv0 = wconst[0], sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;  // src/divergence.rs:44
     const double puu = p_uu_est(al, be);                     // src/divergence.rs:92 (early: overlaps P2)
@@ -487,7 +564,8 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
     // this lane's first triple is fetched before the power table is built and every later one a round ahead:
     // the LDS latency of the triple list stays off the path
     uint32_t tr = STREAM ? a.tri[gl < K ? gl : 0] : tri_s[gl < K ? gl : 0];
-    build_power_table<G>(Gm, a.T, TP, pw, gl);               // P2
+    if constexpr (kMatrixFma && G == kWave) build_power_table_mx<G>(al, be, a.T, lds, a.chain_stride, dtab, lane);  // P1 + P2
+    else build_power_table<G>(genmatrix(al, be), a.T, TP, pw, gl);
     __syncthreads();
     ABN_STAMP(1);
     if (!STREAM) {                                           // P3: ceil(K/G) rounds, one triple per lane
@@ -940,14 +1018,14 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
   auto eval = [&](double xd) -> double {
     const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
     const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
-    const Gen Gm = genmatrix(al, be);                        // P1
     const double p_mm = wconst[1];
     const double sv0 = wconst[0], sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;  // src/divergence.rs:44
     const double puu = p_uu_est(al, be);                     // src/divergence.rs:92
     const double dq = puu - wconst[2];
     const double pen = wconst[3] * (dq * dq);                // src/structs.rs:210-212
     uint32_t tr = tri_s[gl < K ? gl : 0];                    // first triple early, later ones a round ahead
-    build_power_table<G>(Gm, a.T, TP, pw, gl);               // P2
+    if constexpr (kMatrixFma && G == kWave) build_power_table_mx<G>(al, be, a.T, lds, a.chain_stride, dtab, lane);  // P1 + P2
+    else build_power_table<G>(genmatrix(al, be), a.T, TP, pw, gl);
     __syncthreads();
 #pragma unroll 1
     for (int t = gl; t < K; t += G) {                        // P3
@@ -1215,14 +1293,14 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
     ABN_STAMP(6);  // control flow + candidate fetch since the exchange
     const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
     const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
-    const Gen Gm = genmatrix(al, be);
     const double p_mm = wconst[1];
     const double sv0 = wconst[0], sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;
     const double puu = p_uu_est(al, be);
     const double dq = puu - wconst[2];
     const double pen = wconst[3] * (dq * dq);
     ABN_STAMP(0);
-    build_power_table<G>(Gm, a.T, TP, pw, gl);
+    if constexpr (kMatrixFma) build_power_table_mx<G>(al, be, a.T, pw, 0, dtab, gl);  // one chain per wavefront: block 0
+    else build_power_table<G>(genmatrix(al, be), a.T, TP, pw, gl);
     wave_lds_fence();
     ABN_STAMP(1);
 #pragma unroll
@@ -1534,9 +1612,9 @@ struct SelectArgs {
 __device__ __forceinline__ void select_fill_dt(const SelectArgs& a, const double* x, double p_uu0, double* pw,
                                                double* dtab, int lane) {
   const double p_mm = 1.0 - p_uu0;
-  const Gen Gm = genmatrix(x[0], x[1]);
   const double sv0 = p_uu0, sv1 = x[2] * p_mm, sv2 = (1.0 - x[2]) * p_mm;
-  build_power_table<kWave>(Gm, a.T, a.TP, pw, lane);
+  if constexpr (kMatrixFma) build_power_table_mx<kWave>(x[0], x[1], a.T, pw, 0, dtab, lane);
+  else build_power_table<kWave>(genmatrix(x[0], x[1]), a.T, a.TP, pw, lane);
   __syncthreads();
   for (int t = lane; t < a.K; t += kWave) dtab[t] = triple_dt(a.tri[t], pw, a.TP, sv0, sv1, sv2);
   __syncthreads();
@@ -1658,9 +1736,9 @@ __global__ __launch_bounds__(kWave) void abn_cost_kernel(const CostArgs a) {
     const size_t b = a.cand_to_boot ? a.cand_to_boot[m] : (size_t)m;
     idx_row = a.idx + b * (size_t)N;
   }
-  const Gen Gm = genmatrix(al, be);
   const double sv0 = a.p_uu0, sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;
-  build_power_table<G>(Gm, a.T, TP, pw, gl);
+  if constexpr (kMatrixFma && G == kWave) build_power_table_mx<G>(al, be, a.T, lds, a.chain_stride, dtab, lane);
+  else build_power_table<G>(genmatrix(al, be), a.T, TP, pw, gl);
   __syncthreads();
   for (int t = gl; t < K; t += G) dtab[t] = triple_dt(a.tri[t], pw, TP, sv0, sv1, sv2);
   __syncthreads();
