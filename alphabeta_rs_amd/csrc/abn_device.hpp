@@ -337,10 +337,22 @@ __device__ __forceinline__ void build_power_table_mx(double al, double be, int T
     dst[h] += step[h];
     if (T >= 1) dst[h][0] = B[h];             // matrix.clone(), :25
   }
-  for (int n = 2; n <= T; ++n) {              // :27-29
+  // :27-29.  Power n is stored while the instruction for power n+1 runs (the store needs the finished result
+  // anyway; issued right behind the dependent MFMA it hides in its 48-cycle shadow).
+  if (T >= 2) {
+#pragma unroll
+    for (int h = 0; h < NH; ++h) B[h] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[h], B[h], 0.0, 0, 0, 0);
+    for (int n = 3; n <= T; ++n) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        const double nxt = __builtin_amdgcn_mfma_f64_4x4x4f64(A[h], B[h], 0.0, 0, 0, 0);
+        dst[h] += step[h];
+        dst[h][0] = B[h];
+        B[h] = nxt;
+      }
+    }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      B[h] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[h], B[h], 0.0, 0, 0, 0);
       dst[h] += step[h];
       dst[h][0] = B[h];
     }
