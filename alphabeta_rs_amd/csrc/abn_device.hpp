@@ -339,6 +339,7 @@ __device__ __forceinline__ void build_power_table_mx(double al, double be, int T
   }
   // :27-29.  Power n is stored while the instruction for power n+1 runs (the store needs the finished result
   // anyway; issued right behind the dependent MFMA it hides in its 48-cycle shadow).
+  // (build_power_table_mx_pre below repeats this loop for one chain.)
   if (T >= 2) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) B[h] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[h], B[h], 0.0, 0, 0, 0);
@@ -356,6 +357,29 @@ __device__ __forceinline__ void build_power_table_mx(double al, double be, int T
       dst[h] += step[h];
       dst[h][0] = B[h];
     }
+  }
+}
+
+// One chain per wavefront with A = G^T and B = (G^1)^T already in the matrix-instruction layout (zeros outside the
+// 3x3 block of block 0): the speculative kernel's keeper prepares them for every candidate it hands out.
+__device__ __forceinline__ void build_power_table_mx_pre(double A, double B, int T, double* pw, double* dump, int lane) {
+  const int x = lane & 3, blk = (lane >> 2) & 3, y = lane >> 4;
+  const bool st = (x < 3) && (y < 3) && (blk == 0);
+  double* dst = st ? pw + 3 * x + y : dump;
+  const int step = st ? 9 : 0;
+  dst[0] = (x == y) ? 1.0 : 0.0;              // identity, :21-24
+  dst += step;
+  if (T >= 1) dst[0] = B;                     // matrix.clone(), :25
+  if (T >= 2) {                               // :27-29
+    B = __builtin_amdgcn_mfma_f64_4x4x4f64(A, B, 0.0, 0, 0, 0);
+    for (int n = 3; n <= T; ++n) {
+      const double nxt = __builtin_amdgcn_mfma_f64_4x4x4f64(A, B, 0.0, 0, 0, 0);
+      dst += step;
+      dst[0] = B;
+      B = nxt;
+    }
+    dst += step;
+    dst[0] = B;
   }
 }
 
@@ -1248,7 +1272,9 @@ __device__ __forceinline__ void wave_lds_fence() {  // orders this wavefront's L
 
 constexpr int kSpecOutcomes = 10;                                   // r@0..3, e@0, c@0..4
 constexpr int kSpecTabDoubles = kSpecOutcomes * 12;                 // [outcome][candidate r/e/c][dimension]
-constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16;      // cost exchange, two tables, shrink points
+constexpr int kSpecPreDoubles = kSpecOutcomes * 3 * 12;             // [outcome][candidate][G (9), penalty, 0.0, pad]
+constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16 + 2 * kSpecPreDoubles;  // cost exchange, two candidate
+                                                                    // tables, shrink points, two tables of prepared inputs
 
 template <int RMAX>
 __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a) {
@@ -1269,6 +1295,7 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
   double* xch = lds + (size_t)3 * a.chain_stride;  // two buffers of 3 costs (+ pad)
   double* tab = xch + 8;                           // two candidate tables
   double* pts = tab + 2 * kSpecTabDoubles;         // NelderMead::shrink: the four moved vertices
+  double* gtab = pts + 16;                         // per candidate: generation matrix, penalty term, a zero
 
   const int wi = w * a.wstride;
   const size_t wN = (size_t)w * (size_t)N;
@@ -1301,18 +1328,32 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
   unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
 #endif
-  auto eval = [&](double xd) -> double {
+  // Inputs of the next evaluation that depend on (alpha, beta) only and that the keeper prepares next to the
+  // candidate (kMatrixFma builds): this lane's elements of G^T and G in the matrix-instruction layout, the
+  // equilibrium penalty term.  `pre` = they are valid for the candidate being evaluated.
+  double preA = 0.0, preB = 0.0, prePen = 0.0;
+  const int mx_x = gl & 3, mx_y = gl >> 4;
+  const bool mx_in = (mx_x < 3) && (mx_y < 3) && (((gl >> 2) & 3) == 0);
+  const int preA_idx = mx_in ? 3 * mx_y + mx_x : 10, preB_idx = mx_in ? 3 * mx_x + mx_y : 10;  // [10] holds 0.0
+  auto eval = [&](double xd, bool pre) -> double {
     ABN_STAMP(6);  // control flow + candidate fetch since the exchange
-    const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
     const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
     const double p_mm = wconst[1];
     const double sv0 = wconst[0], sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;
-    const double puu = p_uu_est(al, be);
-    const double dq = puu - wconst[2];
-    const double pen = wconst[3] * (dq * dq);
-    ABN_STAMP(0);
-    if constexpr (kMatrixFma) build_power_table_mx<G>(al, be, a.T, pw, 0, dtab, gl);  // one chain per wavefront: block 0
-    else build_power_table<G>(genmatrix(al, be), a.T, TP, pw, gl);
+    double pen;
+    if (kMatrixFma && pre) {
+      pen = prePen;
+      ABN_STAMP(0);
+      build_power_table_mx_pre(preA, preB, a.T, pw, dtab, gl);
+    } else {
+      const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
+      const double puu = p_uu_est(al, be);
+      const double dq = puu - wconst[2];
+      pen = wconst[3] * (dq * dq);
+      ABN_STAMP(0);
+      if constexpr (kMatrixFma) build_power_table_mx<G>(al, be, a.T, pw, 0, dtab, gl);  // one chain per wavefront: block 0
+      else build_power_table<G>(genmatrix(al, be), a.T, TP, pw, gl);
+    }
     wave_lds_fence();
     ABN_STAMP(1);
 #pragma unroll
@@ -1405,15 +1446,51 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
   const int o_kind = oq < 4 ? 0 : (oq == 4 ? 1 : 2);
   const int o_rank = oq < 4 ? oq : (oq == 4 ? 0 : oq - 5);
 
+  // keeper: generation matrix and penalty term of the three candidates (r_, e_, c_: this lane's dimension) of
+  // outcome slot `oq` — lane (quad, dimension t < 3) works for candidate t; same functions as the evaluation
+  // wavefronts would call, so the same bits
+  auto emit_pre = [&](double r_, double e_, double c_, int parity) {
+    const double ar = dpp_mov<kDppQuadBcast0>(r_), br = dpp_mov<kDppQuadBcast1>(r_);
+    const double ae = dpp_mov<kDppQuadBcast0>(e_), be = dpp_mov<kDppQuadBcast1>(e_);
+    const double ac = dpp_mov<kDppQuadBcast0>(c_), bc = dpp_mov<kDppQuadBcast1>(c_);
+    const double al_t = dim == 0 ? ar : (dim == 1 ? ae : ac);
+    const double be_t = dim == 0 ? br : (dim == 1 ? be : bc);
+    const Gen Gt = genmatrix(al_t, be_t);
+    const double puu = p_uu_est(al_t, be_t);
+    const double dq = puu - wconst[2];
+    const double pen = wconst[3] * (dq * dq);
+    if (oq < kSpecOutcomes && dim < 3) {
+      double* g = gtab + parity * kSpecPreDoubles + (oq * 3 + dim) * 12;
+      g[0] = Gt.g0;
+      g[1] = Gt.g1;
+      g[2] = Gt.g2;
+      g[3] = Gt.g3;
+      g[4] = Gt.g4;
+      g[5] = Gt.g5;
+      g[6] = Gt.g6;
+      g[7] = Gt.g7;
+      g[8] = Gt.g8;
+      g[9] = pen;
+      g[10] = 0.0;
+    }
+  };
+  // evaluation wavefronts: the prepared inputs of candidate (outcome o, this wavefront) next to the candidate itself
+  auto fetch_pre = [&](int o, int parity) {
+    const double* g = gtab + parity * kSpecPreDoubles + (o * 3 + wv) * 12;
+    preA = g[preA_idx];
+    preB = g[preB_idx];
+    prePen = g[9];
+  };
+
   // ---- Solver::init: the five start costs in input order (3 + 2), stable sort, first termination check
   double cand = keeper ? 0.0 : s0[4 * wv + dim];
   double f0, f1, f2;
-  exchange(keeper ? 0.0 : eval(cand), f0, f1, f2);
+  exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
   c[0] = f0;
   c[1] = f1;
   c[2] = f2;
   cand = keeper ? 0.0 : s0[4 * (wv == 0 ? 3 : 4) + dim];
-  exchange(keeper ? 0.0 : eval(cand), f0, f1, f2);
+  exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
   c[3] = f0;
   c[4] = f1;
   evals = 5;
@@ -1442,9 +1519,13 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
           t[4 + dim] = x_e;
           t[8 + dim] = x_c;
         }
+        if constexpr (kMatrixFma) emit_pre(xr, x_e, x_c, par);  // every quad writes its slot; slot 0 is read
       }
       __syncthreads();
-      if (!keeper) cand = tab[par * kSpecTabDoubles + 4 * wv + dim];
+      if (!keeper) {
+        cand = tab[par * kSpecTabDoubles + 4 * wv + dim];
+        if constexpr (kMatrixFma) fetch_pre(0, par);
+      }
       par ^= 1;
       publish = false;
     }
@@ -1471,9 +1552,10 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
         t[4 + dim] = ne;
         t[8 + dim] = nc;
       }
+      if constexpr (kMatrixFma) emit_pre(nr, ne, nc, par);
     }
     double fr, fe, fc;
-    exchange(keeper ? 0.0 : eval(cand), fr, fe, fc);
+    exchange(keeper ? 0.0 : eval(cand, true), fr, fe, fc);
     // ---- NelderMead::next_iter's decision.  Every lane holds the same costs, so the branches are uniform.
     // (Measured alternatives, both slower on a lone wavefront: the costs in scalar registers via
     // v_readfirstlane — SGPR spills —, and the flat predicated form of abn_fit_kernel.)
@@ -1526,6 +1608,7 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
           x_c = t[8 + dim];
         } else {
           cand = t[4 * wv + dim];
+          if constexpr (kMatrixFma) fetch_pre(o, par);
         }
         par ^= 1;
       }
@@ -1552,12 +1635,12 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
       }
       __syncthreads();
       if (!keeper) cand = pts[4 * wv + dim];
-      exchange(keeper ? 0.0 : eval(cand), f0, f1, f2);
+      exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
       c[1] = f0;
       c[2] = f1;
       c[3] = f2;
       if (!keeper) cand = pts[12 + dim];
-      exchange(keeper ? 0.0 : eval(cand), f0, f1, f2);
+      exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
       c[4] = f0;
       evals += 4;
       if (keeper) sort5(c, vx);
