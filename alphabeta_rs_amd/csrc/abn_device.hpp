@@ -1273,8 +1273,8 @@ __device__ __forceinline__ void wave_lds_fence() {  // orders this wavefront's L
 constexpr int kSpecOutcomes = 10;                                   // r@0..3, e@0, c@0..4
 constexpr int kSpecTabDoubles = kSpecOutcomes * 12;                 // [outcome][candidate r/e/c][dimension]
 constexpr int kSpecPreDoubles = kSpecOutcomes * 3 * 12;             // [outcome][candidate][G (9), penalty, 0.0, pad]
-constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16 + 2 * kSpecPreDoubles;  // cost exchange, two candidate
-                                                                    // tables, shrink points, two tables of prepared inputs
+constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16 + 2 * kSpecPreDoubles + 16;  // cost exchange, two candidate
+                                                 // tables, shrink points, two tables of prepared inputs, two control blocks
 
 template <int RMAX>
 __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a) {
@@ -1399,7 +1399,7 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
     ABN_STAMP(4);
   };
 
-  // ---- control state, replicated in all four wavefronts and updated by the same code from the same costs
+  // ---- control state (the keeper's; the evaluation wavefronts hold a published copy of the costs in c[])
   double c[5], best_cost = __builtin_inf();
   bool have_best = false;
   int iter = 0;
@@ -1434,7 +1434,6 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
   // ---- keeper state: the simplex, this lane's dimension of the five vertices in rank order, the three
   // candidates of the running iteration, best_param, evaluation count
   double vx[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, xr = 0.0, x_e = 0.0, x_c = 0.0, bx = __builtin_nan("");
-  double dummy[5] = {0.0, 0.0, 0.0, 0.0, 0.0};  // evaluation wavefronts sort costs only
   int evals = 0;
   const double* s0 = a.simplex0 + (size_t)chain * 20;
   if (keeper) {
@@ -1482,29 +1481,37 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
     prePen = g[9];
   };
 
-  // ---- Solver::init: the five start costs in input order (3 + 2), stable sort, first termination check
-  double cand = keeper ? 0.0 : s0[4 * wv + dim];
-  double f0, f1, f2;
-  exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
-  c[0] = f0;
-  c[1] = f1;
-  c[2] = f2;
-  cand = keeper ? 0.0 : s0[4 * (wv == 0 ? 3 : 4) + dim];
-  exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
-  c[3] = f0;
-  c[4] = f1;
-  evals = 5;
-  if (keeper) sort5(c, vx);
-  else sort5(c, dummy);
+  // ---- The keeper alone keeps the optimiser's state.  What the evaluation wavefronts need to follow the control
+  // flow it publishes in `ctl` (two buffers): the five sorted costs BEFORE the running iteration (their decision
+  // needs c0, c3, c4 and the rank of the accepted cost) and a `done` flag.  The keeper writes ctl[cb] while the
+  // others evaluate; they read it behind the next exchange barrier, then everybody flips cb.  The flag therefore
+  // reaches them one evaluation late: a finished fit costs one surplus evaluation (never counted, never used),
+  // every iteration saves the cost insertion and the termination test on the evaluation wavefronts' path.
+  double* ctl = gtab + 2 * kSpecPreDoubles;
+  int cb = 0;
+  auto ctl_write = [&](int status_now) {      // keeper
+    if (gl < 5) ctl[8 * cb + gl] = gl == 0 ? c[0] : (gl == 1 ? c[1] : (gl == 2 ? c[2] : (gl == 3 ? c[3] : c[4])));
+    if (gl == 5) ctl[8 * cb + 5] = status_now >= 0 ? 1.0 : 0.0;
+  };
+  auto ctl_read = [&]() -> bool {             // evaluation wavefronts: costs into c[], returns done
+    const double* b = ctl + 8 * cb;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) c[k] = b[k];
+    return b[5] != 0.0;
+  };
   bool improved;
-  int status = ctl_begin(false, improved);
-  if (keeper && improved) bx = vx[0];
-  bool publish = true;  // the keeper hands the candidates of a freshly sorted simplex over directly
+  int status = -1;
   int par = 0;
+  double f0, f1, f2;
+  double cand = 0.0;
 
-  while (status < 0) {
-    if (publish) {
-      if (keeper) {  // centroid (p0 + p1 + p2 + p3) * (1/4), x0 + (x0 - xw) * alpha, x0 + (xr - x0) * gamma, x0 + (xw - x0) * rho
+  // hand-over of a freshly sorted simplex (after Solver::init and after a shrink): the keeper writes the control
+  // block and, unless the fit is finished, the three candidates with their prepared inputs; one barrier; the
+  // evaluation wavefronts learn `done` and pick their candidate up.  Returns done.
+  auto publish = [&]() -> bool {
+    if (keeper) {
+      ctl_write(status);
+      if (status < 0) {  // centroid (p0 + p1 + p2 + p3) * (1/4), x0 + (x0 - xw) * alpha, x0 + (xr - x0) * gamma, x0 + (xw - x0) * rho
         double acc = vx[0];
         acc = acc + vx[1];
         acc = acc + vx[2];
@@ -1521,14 +1528,39 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
         }
         if constexpr (kMatrixFma) emit_pre(xr, x_e, x_c, par);  // every quad writes its slot; slot 0 is read
       }
-      __syncthreads();
-      if (!keeper) {
+    }
+    __syncthreads();
+    bool done = status >= 0;                  // keeper
+    if (!keeper) {
+      done = ctl[8 * cb + 5] != 0.0;
+      if (!done) {
         cand = tab[par * kSpecTabDoubles + 4 * wv + dim];
         if constexpr (kMatrixFma) fetch_pre(0, par);
       }
-      par ^= 1;
-      publish = false;
     }
+    par ^= 1;
+    return done;
+  };
+
+  // ---- Solver::init: the five start costs in input order (3 + 2), stable sort, first termination check
+  cand = keeper ? 0.0 : s0[4 * wv + dim];
+  exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
+  c[0] = f0;
+  c[1] = f1;
+  c[2] = f2;
+  cand = keeper ? 0.0 : s0[4 * (wv == 0 ? 3 : 4) + dim];
+  exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
+  c[3] = f0;
+  c[4] = f1;
+  evals = 5;
+  if (keeper) {
+    sort5(c, vx);
+    status = ctl_begin(false, improved);
+    if (improved) bx = vx[0];
+  }
+  bool done = publish();
+
+  while (!done) {
     if (keeper) {
       // the candidates of the NEXT iteration for each way this one can end.  Outcome (A, p): the accepted
       // point A replaces the worst vertex and sorts in at rank p; the new order is v0..v3 with A at p.
@@ -1556,9 +1588,18 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
     }
     double fr, fe, fc;
     exchange(keeper ? 0.0 : eval(cand, true), fr, fe, fc);
+#ifdef ABN_STAMPS
+    ++seg[7];  // iterations seen by this wavefront
+#endif
+    if (!keeper) {
+      // the sorted costs before this iteration, and whether the keeper finished the fit while this (then surplus)
+      // evaluation ran
+      if (ctl_read()) break;
+    }
+    cb ^= 1;
     // ---- NelderMead::next_iter's decision.  Every lane holds the same costs, so the branches are uniform.
-    // (Measured alternatives, both slower on a lone wavefront: the costs in scalar registers via
-    // v_readfirstlane — SGPR spills —, and the flat predicated form of abn_fit_kernel.)
+    // (Measured alternatives, all slower on a lone wavefront: the costs in scalar registers via v_readfirstlane —
+    // persistent: SGPR spills; re-read every iteration: +23 % —, and the flat predicated form of abn_fit_kernel.)
     int kind, which = 0;   // kind 0: a point is accepted, 1: rejected contraction (simplex untouched), 2: shrink
     double fi = fr;
     int spent;             // cost() calls the reference makes in this branch
@@ -1589,40 +1630,38 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
       // rank of the accepted point: the stable insertion of insert_tail<4>
       const bool b3 = fi < c[3], b2 = b3 && (fi < c[2]), b1 = b2 && (fi < c[1]), b0 = b1 && (fi < c[0]);
       const int p = 4 - ((b3 ? 1 : 0) + (b2 ? 1 : 0) + (b1 ? 1 : 0) + (b0 ? 1 : 0));
-      c[4] = fi;
+      const int o = which == 0 ? p : (which == 1 ? 4 : 5 + p);
+      const double* t = tab + par * kSpecTabDoubles + o * 12;
       if (keeper) {
+        c[4] = fi;
         vx[4] = which == 0 ? xr : (which == 1 ? x_e : x_c);
         insert_tail<4>(c, vx);
+        status = ctl_begin(true, improved);
+        if (improved) bx = vx[0];
+        ctl_write(status);
+        xr = t[dim];
+        x_e = t[4 + dim];
+        x_c = t[8 + dim];
       } else {
-        insert_tail<4>(c, dummy);
+        cand = t[4 * wv + dim];
+        if constexpr (kMatrixFma) fetch_pre(o, par);
+        ABN_STAMP(5);  // decision
       }
-      status = ctl_begin(true, improved);
-      if (keeper && improved) bx = vx[0];
-      ABN_STAMP(5);  // decision, cost insert, termination
-      if (status < 0) {
-        const int o = which == 0 ? p : (which == 1 ? 4 : 5 + p);
-        const double* t = tab + par * kSpecTabDoubles + o * 12;
-        if (keeper) {
-          xr = t[dim];
-          x_e = t[4 + dim];
-          x_c = t[8 + dim];
-        } else {
-          cand = t[4 * wv + dim];
-          if constexpr (kMatrixFma) fetch_pre(o, par);
-        }
-        par ^= 1;
-      }
+      par ^= 1;
     } else if (kind == 1) {
       // argmin 0.8.1: a rejected contraction leaves the simplex untouched — for good: every later iteration
       // repeats this one.  no_skip == 0: finish the chain with the counters it would reach (FitArgs::no_skip)
-      if (a.no_skip == 0) {
-        const int rest = a.max_iters - iter - 1;
-        evals += 2 * rest;
-        iter += rest;
-        if (a.skipped && keeper && gl == 0 && rest > 0) atomicAdd(a.skipped, 2ull * (unsigned long long)rest);
+      if (keeper) {
+        if (a.no_skip == 0) {
+          const int rest = a.max_iters - iter - 1;
+          evals += 2 * rest;
+          iter += rest;
+          if (a.skipped && gl == 0 && rest > 0) atomicAdd(a.skipped, 2ull * (unsigned long long)rest);
+        }
+        status = ctl_begin(true, improved);
+        ctl_write(status);
       }
-      status = ctl_begin(true, improved);
-      par ^= 1;  // same candidates again; the keeper rebuilds the (identical) table in the other buffer
+      par ^= 1;  // same candidates again; the keeper rebuilds the (identical) tables in the other buffers
     } else {
       // NelderMead::shrink (NaN reflection cost, or the textbook variant after a rejected contraction):
       // vertices 1..4 move towards the best by sigma and are re-evaluated in order (3 + 1)
@@ -1643,18 +1682,25 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
       exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
       c[4] = f0;
       evals += 4;
-      if (keeper) sort5(c, vx);
-      else sort5(c, dummy);
-      status = ctl_begin(true, improved);
-      if (keeper && improved) bx = vx[0];
-      publish = true;
+      if (keeper) {
+        sort5(c, vx);
+        status = ctl_begin(true, improved);
+        if (improved) bx = vx[0];
+      }
+      done = publish();
+      continue;
+    }
+    // the keeper found the fit finished: the others are one evaluation ahead — meet them at that exchange
+    if (keeper && status >= 0) {
+      exchange(0.0, f0, f1, f2);
+      break;
     }
   }
 
 #ifdef ABN_STAMPS
   if (a.dbg && chain == 0 && wv == 0 && gl == 0) {
     for (int q = 0; q < 8; ++q) a.dbg[q] = seg[q];
-    a.dbg[7] = (unsigned long long)iter;
+    a.dbg[7] = seg[7];
   }
 #endif
   const double b0 = dpp_mov<kDppQuadBcast0>(bx), b1 = dpp_mov<kDppQuadBcast1>(bx);
