@@ -1587,14 +1587,37 @@ __global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a
       if constexpr (kMatrixFma) emit_pre(nr, ne, nc, par);
     }
     double fr, fe, fc;
-    exchange(keeper ? 0.0 : eval(cand, true), fr, fe, fc);
+    {  // exchange + (evaluation wavefronts) the control block, read in ONE batch of LDS loads behind the barrier:
+       // the sorted costs before this iteration, and whether the keeper finished the fit while this (then surplus)
+       // evaluation ran
+      const double f = keeper ? 0.0 : eval(cand, true);
+      double* buf = xch + 4 * phase;
+      if (!keeper && gl == 0) buf[wv] = f;
+      __syncthreads();
+      const double* b = ctl + 8 * cb;
+      fr = buf[0];
+      fe = buf[1];
+      fc = buf[2];
+      double k0 = c[0], k1 = c[1], k2 = c[2], k3 = c[3], k4 = c[4], dn = 0.0;
+      if (!keeper) {
+        k0 = b[0];
+        k1 = b[1];
+        k2 = b[2];
+        k3 = b[3];
+        k4 = b[4];
+        dn = b[5];
+      }
+      c[0] = k0;
+      c[1] = k1;
+      c[2] = k2;
+      c[3] = k3;
+      c[4] = k4;
+      phase ^= 1;
+      ABN_STAMP(4);
 #ifdef ABN_STAMPS
-    ++seg[7];  // iterations seen by this wavefront
+      ++seg[7];  // iterations seen by this wavefront
 #endif
-    if (!keeper) {
-      // the sorted costs before this iteration, and whether the keeper finished the fit while this (then surplus)
-      // evaluation ran
-      if (ctl_read()) break;
+      if (dn != 0.0) break;
     }
     cb ^= 1;
     // ---- NelderMead::next_iter's decision.  Every lane holds the same costs, so the branches are uniform.
