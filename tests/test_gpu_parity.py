@@ -633,7 +633,7 @@ def test_fixed_point_skip_changes_no_output(abn, gpu_ctx, golden, oracle):
         _assert_fits_equal(res[0][0], res[0][1], want)
 
 
-@pytest.mark.parametrize("variant,no_skip,iters", ((1, 0, 10000), (0, 1, 400), (0, 0, 10000)))
+@pytest.mark.parametrize("variant,no_skip,iters", ((1, 0, 10000), (0, 1, 400), (0, 0, 10000), (0, 0, 0), (0, 1, 1), (1, 0, 2)))
 def test_speculative_phase_a_all_branches(abn, gpu_ctx, golden, oracle, variant, no_skip, iters):
     """Phase A of a small plan runs on abn_fit_spec_kernel (three evaluation wavefronts + the keeper).  Its
     rare branches — NelderMead::shrink after a NaN reflection cost or, in the textbook variant, after a
