@@ -119,11 +119,11 @@ def cpu_baseline(wl, model, pred, resid, lanes, seed, evals_per_fit, budget_s=12
     nb, iters = cores, 4                                # probe: 5 + <= 8 evaluations per fit and thread
     for _ in range(5):
         dt, ev = run(nb, iters, False)
-        if dt >= budget_s / 3.0:
+        if dt >= 0.75 * budget_s:
             break
         target = ev / dt * budget_s                     # evaluations the budget buys at the measured rate
         if target >= 4.0 * cores * evals_per_fit:       # whole fits: >= 4 per thread
-            nb, iters = int(min(1024.0 * cores, target / evals_per_fit)), 1000
+            nb, iters = int(min(8192.0 * cores, target / evals_per_fit)), 1000
         else:                                           # truncated fits, one per thread
             nb, iters = cores, max(4, int(target / cores / 1.7) - 5)
     dt_t, ev_t = run(nb, iters, True)
