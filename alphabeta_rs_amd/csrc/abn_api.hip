@@ -140,7 +140,10 @@ constexpr size_t kLdsResidentMax = 40 * 1024;
 #define ABN_PERSIST_WAVES 3072
 #endif
 constexpr long long kPersistWaves = ABN_PERSIST_WAVES;  // wavefronts of a persistent launch: 3 per SIMD x 4 SIMDs x 256 CUs
-constexpr long long kPhaseASpecMax = 1024;  // start chains up to which phase A uses abn_fit_spec_kernel
+#ifndef ABN_PHASE_A_SPEC_MAX
+#define ABN_PHASE_A_SPEC_MAX 1024
+#endif
+constexpr long long kPhaseASpecMax = ABN_PHASE_A_SPEC_MAX;  // start chains up to which phase A uses abn_fit_spec_kernel
 constexpr long long kPhaseAWideMax = 6144;  // ... and up to which it uses one wavefront per chain
 constexpr int kPhaseACap = 1000;  // first-pass iteration cap of the two-pass phase A  // above this the fit kernel streams rows instead of staging them
 

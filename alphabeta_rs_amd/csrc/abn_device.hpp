@@ -1277,7 +1277,7 @@ constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16 + 2 * kSpecPreDoub
                                                  // tables, shrink points, two tables of prepared inputs, two control blocks
 
 template <int RMAX>
-__global__ __launch_bounds__(4 * kWave) void abn_fit_spec_kernel(const FitArgs a) {
+__global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_kernel(const FitArgs a) {
   constexpr int G = kWave;
   extern __shared__ __align__(16) double lds[];
   const int wv = threadIdx.x >> 6;      // 0: reflection, 1: expansion, 2: contraction, 3: keeper
