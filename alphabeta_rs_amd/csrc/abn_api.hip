@@ -697,8 +697,9 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   p->lanes_a = p->lanes;
   // Phase A is latency-bound while its chains fit the machine about twice over (3 wavefronts x 1024 SIMDs): one
   // wavefront per chain then beats packing several chains into a wavefront, and below ~1000 chains the
-  // four-wavefront speculative kernel beats both (scripts/phase_a_sweep.py, C3 topology: 1000 chains 3.2 / 3.4 /
-  // 5.1 ms for speculative / 64 lanes / 16 lanes; 4000 chains - / 5.2 / 6.6 ms; 8000 chains - / 7.7 / 7.0 ms)
+  // four-wavefront speculative kernel beats both (scripts/phase_a_sweep.py, C3 topology: 1000 chains 2.6 / 3.2 /
+  // 4.6 ms for speculative / 64 lanes / 16 lanes, 1500 chains 4.2 / 3.4 / 4.8; 4000 chains - / 4.6 / 5.9 ms;
+  // 8000 chains - / 7.7 / 7.0 ms)
   if (p->opt.lanes_per_chain == 0 && (long long)n_windows * n_starts <= kPhaseAWideMax) p->lanes_a = 64;
   if ((size_t)(kWave / p->lanes) * p->topo.chain_stride * sizeof(double) > kMaxDynLds ||
       ((size_t)p->topo.chain_stride + kSelChunk) * sizeof(double) > kMaxDynLds) {
