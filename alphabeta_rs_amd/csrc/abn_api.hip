@@ -249,8 +249,16 @@ static bool fit_streams(int n, int chain_stride, int lanes) {
 
 // Speculative kernel (phase A; three evaluation wavefronts + a bookkeeping wavefront per chain): resident mode
 // with one wavefront per candidate only.
+// Chains up to which the speculative kernel is used: 4/3 of what the GPU holds at once (three workgroups per CU
+// for pedigrees of up to two rows per lane, else two: the kernel's register budget).  Measured (scripts/phase_a_sweep.py,
+// C3 topology): 1000 chains 2.6 ms against 3.2 ms with one wavefront per chain, 1500 chains 4.2 against 3.4; the
+// 351-row golden pedigree with 1000 bootstraps: 2.8 ms against 2.0 ms.
+static long long spec_max_chains(int n_rows) {
+  return pick_rmax(n_rows, kWave) <= 2 ? kPhaseASpecMax : kPhaseASpecMax * 2 / 3;
+}
+
 static bool spec_applicable(const FitArgs& a) {
-  if (a.dmode != 0 || a.smode != 0) return false;
+  if (a.dmode == 2) return false;  // resident observations only (starts, or bootstraps gathered through the index row)
   const int rmax = pick_rmax(a.N, kWave);
   if (rmax == 0 || rmax > 8) return false;  // 16 rows per lane: the plain resident kernel
   const int np = (a.N + 1) & ~1;
@@ -858,7 +866,7 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   if (timed) HIPCHK(c, hipEventRecord(p->ev[0], st));
   // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once,
   // a fourth keeps the simplex and prepares the next candidates meanwhile (abn_fit_spec_kernel)
-  const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && (long long)p->W * p->S <= kPhaseASpecMax &&
+  const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && (long long)p->W * p->S <= spec_max_chains(p->N) &&
                     spec_applicable(a);
   int rc;
   if (spec) {
@@ -944,7 +952,10 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
     a.dmode = 2;
     a.D = dst;
   }
-  int rc = launch_fit(c, a, p->lanes, st);
+  // few bootstraps: latency-bound like phase A -> the speculative kernel (four wavefronts per chain)
+  const bool spec = a.dmode == 1 && p->opt.lanes_per_chain == 0 && (long long)p->W * p->B <= spec_max_chains(p->N) &&
+                    spec_applicable(a);
+  int rc = spec ? launch_fit_spec(c, a, st) : launch_fit(c, a, p->lanes, st);
   if (rc) return rc;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[5], st));
   return ABN_OK;

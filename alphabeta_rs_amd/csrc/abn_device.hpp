@@ -1304,6 +1304,8 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
   for (int q = 0; q < (RMAX + 1) / 2; ++q) tidp[q] = 0u;
 #pragma unroll
   for (int q = 0; q < RMAX; ++q) triv[q] = 0u;
+  // keeper state: the simplex, this lane's dimension of the five vertices in rank order
+  double vx[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   if (!keeper) {
     if (gl == 0) {
       const double p_uu0 = a.p_uu[wi];
@@ -1312,14 +1314,41 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
       wconst[2] = a.eqp[wi];
       wconst[3] = a.eqp_w[wi] * (double)N;
     }
+    const uint32_t* idx_row = (a.dmode == 1) ? a.idx + (size_t)chain * (size_t)N : nullptr;
 #pragma unroll
     for (int q = 0; q < RMAX; ++q) {
       const int i = gl + G * q;
       triv[q] = (i < K) ? a.tri[i] : 0u;
       if (i < N) {
         tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
-        dobs[i] = a.D[wN + i];  // phase-A observations (dmode 0); bootstraps use abn_fit_kernel
+        dobs[i] = (a.dmode == 1) ? a.pred[wN + i] + a.resid[wN + idx_row[i]]  // src/boot_model.rs:50-54
+                                 : a.D[wN + i];
       }
+    }
+  } else {
+    // start simplex (starts: given; bootstraps: [params, vary() x4], src/boot_model.rs:69-75), handed to the
+    // evaluation wavefronts through the (still unused) candidate table
+    if (a.smode == 0) {
+      const double* s0 = a.simplex0 + (size_t)chain * 20;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) vx[k] = s0[4 * k + dim];
+    } else {
+      const int j = (int)(chain - (long long)w * a.C);
+      const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+      const uint32_t wg = a.window_offset + (uint32_t)w, bg = a.boot_offset + (uint32_t)j;
+      vx[0] = a.model[4 * w + dim];
+#pragma unroll
+      for (int v = 1; v < 5; ++v) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)(v - 1) * 2u + (uint32_t)(dim >> 1), bg, wg, kTagJitter, k0, k1, r);
+        const uint32_t r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        const bool odd = (dim & 1) != 0;
+        vx[v] = vary_one(vx[0], odd ? r2 : r0, odd ? r3 : r1);
+      }
+    }
+    if (gl < 4) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) tab[4 * k + dim] = vx[k];
     }
   }
   __syncthreads();
@@ -1433,13 +1462,8 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
 
   // ---- keeper state: the simplex, this lane's dimension of the five vertices in rank order, the three
   // candidates of the running iteration, best_param, evaluation count
-  double vx[5] = {0.0, 0.0, 0.0, 0.0, 0.0}, xr = 0.0, x_e = 0.0, x_c = 0.0, bx = __builtin_nan("");
+  double xr = 0.0, x_e = 0.0, x_c = 0.0, bx = __builtin_nan("");
   int evals = 0;
-  const double* s0 = a.simplex0 + (size_t)chain * 20;
-  if (keeper) {
-#pragma unroll
-    for (int k = 0; k < 5; ++k) vx[k] = s0[4 * k + dim];
-  }
   // the keeper's lane group: quad q < 10 works on outcome q = (accepted point, rank): r@0..3, e@0, c@0..4
   const int oq = gl >> 2;
   const int o_kind = oq < 4 ? 0 : (oq == 4 ? 1 : 2);
@@ -1493,12 +1517,6 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
     if (gl < 5) ctl[8 * cb + gl] = gl == 0 ? c[0] : (gl == 1 ? c[1] : (gl == 2 ? c[2] : (gl == 3 ? c[3] : c[4])));
     if (gl == 5) ctl[8 * cb + 5] = status_now >= 0 ? 1.0 : 0.0;
   };
-  auto ctl_read = [&]() -> bool {             // evaluation wavefronts: costs into c[], returns done
-    const double* b = ctl + 8 * cb;
-#pragma unroll
-    for (int k = 0; k < 5; ++k) c[k] = b[k];
-    return b[5] != 0.0;
-  };
   bool improved;
   int status = -1;
   int par = 0;
@@ -1543,12 +1561,12 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
   };
 
   // ---- Solver::init: the five start costs in input order (3 + 2), stable sort, first termination check
-  cand = keeper ? 0.0 : s0[4 * wv + dim];
+  cand = keeper ? 0.0 : tab[4 * wv + dim];
   exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
   c[0] = f0;
   c[1] = f1;
   c[2] = f2;
-  cand = keeper ? 0.0 : s0[4 * (wv == 0 ? 3 : 4) + dim];
+  cand = keeper ? 0.0 : tab[4 * (wv == 0 ? 3 : 4) + dim];
   exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
   c[3] = f0;
   c[4] = f1;
