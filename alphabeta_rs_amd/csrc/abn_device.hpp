@@ -1245,22 +1245,23 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Speculative fit kernel for the latency-bound case (few chains, e.g. the S starts of phase A).
+// Speculative fit kernel for the latency-bound case (few chains: the S starts of phase A, a few hundred bootstraps).
 // A Nelder-Mead iteration evaluates the reflection and then, depending on its cost, the expansion OR the
 // contraction point (argmin next_iter) — two dependent evaluations on ~70 % of the iterations.  All three
 // candidates are known before the first cost: x_r = x0 + (x0 - x_w), x_e = x0 + 2 (x_r - x0),
 // x_c = x0 + (x_w - x0)/2.  Here a chain owns a workgroup of FOUR wavefronts, one per SIMD of a CU:
 //   * wavefronts 0..2 evaluate one candidate each with the G = 64 tree and exchange the three costs through
-//     LDS.  Of the Nelder-Mead state they keep only what the control flow needs — the five sorted costs, the
-//     best cost and the iteration count — and take the reference's decision on them.
-//   * wavefront 3, the "keeper", owns the simplex (dimension per lane).  While the others evaluate the
-//     candidates of iteration i it works out, for every way iteration i can end — the accepted point is the
-//     reflection, expansion or contraction and lands at rank p of the new order: ten outcomes, one per quad
-//     of lanes — the three candidates of iteration i+1, and leaves them in LDS.  After the exchange an
-//     evaluation wavefront picks its next candidate from that table with one LDS read instead of doing the
-//     simplex update itself (which, on a lone wavefront, cost as much as 2/3 of an evaluation).
-// All four wavefronts derive the control flow from the same costs with the same code, so they reach the same
-// barriers.  Results, iteration and evaluation counts (only evaluations the reference would have made are
+//     LDS.  They hold no optimiser state: behind the exchange barrier they read the sorted costs of the previous
+//     update and a done flag (published by the keeper), take the reference's decision — which point is accepted
+//     and at which rank it sorts in: one of ten outcomes — and pick their next candidate, its generation-matrix
+//     elements (matrix-instruction layout) and its penalty term out of tables.
+//   * wavefront 3, the "keeper", alone holds the simplex (dimension per lane), costs, best vertex and counters.
+//     While the others evaluate the candidates of iteration i it works out, for each of the ten outcomes (one per
+//     quad of lanes), the three candidates of iteration i+1 and what depends on their (alpha, beta) only, and
+//     publishes the costs / done flag of the update it made after iteration i-1.
+// The done flag reaches the evaluation wavefronts one evaluation late (a finished fit costs one surplus evaluation,
+// never counted); every wavefront derives its control flow from the same published numbers, so they reach the
+// same barriers.  Results, iteration and evaluation counts (only evaluations the reference would have made are
 // counted) are bit-identical to abn_fit_kernel<64,*>.
 // Resident mode only (N <= 64*RMAX).  LDS: 3 x chain_stride doubles + kSpecCommDoubles.
 // ------------------------------------------------------------------------------------------------
