@@ -46,6 +46,10 @@ EXPORTED_SYMBOLS = [
     "abn_analyze", "abn_select_best", "abn_bootstrap_rows", "abn_pairwise_divergence", "abn_plan_create", "abn_plan_destroy", "abn_plan_set_windows", "abn_plan_run",
     "abn_plan_run_phase", "abn_plan_sync", "abn_plan_kernel_ms", "abn_plan_raw_device_ptr",
     "abn_plan_bind_raw", "abn_plan_download", "abn_plan_counters", "abn_plan_device_bytes",
+    "abn_plan_set_window_ids", "abn_plan_failed_windows",
+    "abn_multi_create", "abn_multi_destroy", "abn_multi_last_error", "abn_multi_set_windows", "abn_multi_run",
+    "abn_multi_sync", "abn_multi_shard", "abn_multi_raw_device_ptr", "abn_multi_download", "abn_multi_counters",
+    "abn_multi_rccl_available", "abn_reduction_tree",
 ]
 
 
@@ -127,6 +131,22 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     L.abn_plan_download.argtypes = [vp, dp, dp, dp, dp, vp, vp, C.POINTER(C.c_int32)]
     L.abn_plan_counters.argtypes = [vp, C.POINTER(C.c_int64)]
     L.abn_plan_device_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.abn_plan_set_window_ids.argtypes = [vp, u32p]
+    L.abn_plan_failed_windows.argtypes = [vp, C.POINTER(C.c_int32)]
+    i32p = C.POINTER(C.c_int32)
+    L.abn_multi_create.argtypes = [i32p, C.c_int32, op, dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    L.abn_multi_destroy.argtypes = [vp]
+    L.abn_multi_last_error.argtypes = [vp]
+    L.abn_multi_last_error.restype = C.c_char_p
+    L.abn_multi_set_windows.argtypes = [vp, dp, dp, dp, dp]
+    L.abn_multi_run.argtypes = [vp]
+    L.abn_multi_sync.argtypes = [vp]
+    L.abn_multi_shard.argtypes = [vp, C.c_int32, i32p]
+    L.abn_multi_raw_device_ptr.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    L.abn_multi_download.argtypes = [vp, dp, dp, dp, dp, vp, vp, i32p]
+    L.abn_multi_counters.argtypes = [vp, C.POINTER(C.c_int64)]
+    L.abn_multi_rccl_available.argtypes = [C.POINTER(C.c_int)]
+    L.abn_reduction_tree.argtypes = [op, dp, C.c_int32, i32p]
     _lib = L
     return L
 
@@ -354,6 +374,17 @@ class Plan:
         except Exception:
             pass
 
+    def set_window_ids(self, ids):
+        """ids[W]: every window's index in the Philox counters (default window_offset + w); before set_windows"""
+        a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32).reshape(self.W)
+        self.ctx._check(self._L.abn_plan_set_window_ids(self._h, _u32p(a)))
+
+    def failed_windows(self) -> int:
+        """windows whose selection found no finite start in the last phase-A run"""
+        n = C.c_int32(0)
+        self.ctx._check(self._L.abn_plan_failed_windows(self._h, C.byref(n)))
+        return n.value
+
     def set_windows(self, d_obs, p0uu, eqp=None, eqp_weight=None):
         d = _f64(d_obs, (self.W, self.N))
         p = _f64(p0uu, (self.W,))
@@ -383,17 +414,21 @@ class Plan:
     def bind_raw(self, dev_ptr: int):
         self.ctx._check(self._L.abn_plan_bind_raw(self._h, C.c_void_p(dev_ptr)))
 
-    def download(self, want_info=True):
+    def download(self, want_info=True, allow_failed_windows=False):
+        """Raises AbnError(ABN_ERR_NO_FINITE_FIT) when a window has no finite start (the reference panics) unless
+        allow_failed_windows: then the dict comes back with best_start = -1 and NaN rows for those windows."""
         W, N, S, B = self.W, self.N, self.S, self.B
         models, pred, resid = np.empty((W, 4)), np.empty((W, N)), np.empty((W, N))
         raw = np.empty((W, B, 7)) if B else None
         ia = np.zeros((W, S), dtype=FIT_INFO_DTYPE) if (S and want_info) else None
         ib = np.zeros((W, B), dtype=FIT_INFO_DTYPE) if (B and want_info) else None
         bs = np.full(W, -1, dtype=np.int32)
-        self.ctx._check(self._L.abn_plan_download(self._h, _dp(models), _dp(pred), _dp(resid), _dp(raw),
-                                                  None if ia is None else ia.ctypes.data,
-                                                  None if ib is None else ib.ctypes.data,
-                                                  bs.ctypes.data_as(C.POINTER(C.c_int32))))
+        rc = self._L.abn_plan_download(self._h, _dp(models), _dp(pred), _dp(resid), _dp(raw),
+                                       None if ia is None else ia.ctypes.data,
+                                       None if ib is None else ib.ctypes.data,
+                                       bs.ctypes.data_as(C.POINTER(C.c_int32)))
+        if not (rc == 5 and allow_failed_windows):  # ABN_ERR_NO_FINITE_FIT: every buffer is filled all the same
+            self.ctx._check(rc)
         return {"models": models, "pred": pred, "resid": resid, "raw": raw, "info_a": ia, "info_b": ib,
                 "best_start": bs}
 
@@ -407,3 +442,94 @@ class Plan:
         b = C.c_int64()
         self.ctx._check(self._L.abn_plan_device_bytes(self._h, C.byref(b)))
         return b.value
+
+
+def reduction_tree(generations, options: Options | None = None) -> int:
+    """The residual reduction tree of a pedigree (abn_fit_info.lanes): host arithmetic, no device needed."""
+    g = _f64(generations).reshape(-1, 3)
+    t = C.c_int32(0)
+    rc = load_library().abn_reduction_tree(C.byref(options) if options else None, _dp(g), g.shape[0], C.byref(t))
+    if rc:
+        raise AbnError(rc)
+    return t.value
+
+
+def rccl_available() -> bool:
+    ok = C.c_int(0)
+    load_library().abn_multi_rccl_available(C.byref(ok))
+    return bool(ok.value)
+
+
+class MultiPlan:
+    """abn_multi: one process, several GPUs — a plan per device, windows (or, with fewer windows than devices,
+    bootstraps) sharded in contiguous blocks, the bootstrap tables gathered with RCCL over xGMI."""
+
+    def __init__(self, devices, generations, n_windows, n_starts, n_boot, *, options: Options | None = None):
+        self._L = load_library()
+        g = _f64(generations).reshape(-1, 3)
+        self.devices = [int(d) for d in devices]
+        self.N, self.W, self.S, self.B = g.shape[0], n_windows, n_starts, n_boot
+        devs = (C.c_int32 * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        rc = self._L.abn_multi_create(devs, len(self.devices), C.byref(options) if options else None, _dp(g), self.N,
+                                      n_windows, n_starts, n_boot, C.byref(h))
+        self._h = h if h.value else None
+        if rc:
+            msg = (self._L.abn_multi_last_error(h) or b"").decode() if h.value else ""
+            self.close()
+            raise AbnError(rc, msg)
+
+    def _check(self, rc):
+        if rc:
+            raise AbnError(rc, (self._L.abn_multi_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.abn_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_windows(self, d_obs, p0uu, eqp=None, eqp_weight=None):
+        d = _f64(d_obs, (self.W, self.N))
+        p = _f64(p0uu, (self.W,))
+        e = None if eqp is None else _f64(eqp, (self.W,))
+        ew = None if eqp_weight is None else _f64(eqp_weight, (self.W,))
+        self._check(self._L.abn_multi_set_windows(self._h, _dp(d), _dp(p), _dp(e), _dp(ew)))
+
+    def run(self):
+        self._check(self._L.abn_multi_run(self._h))
+
+    def sync(self):
+        self._check(self._L.abn_multi_sync(self._h))
+
+    def shard(self, device_index: int):
+        out = (C.c_int32 * 4)()
+        self._check(self._L.abn_multi_shard(self._h, device_index, out))
+        return {"window_offset": out[0], "n_windows": out[1], "boot_offset": out[2], "n_boot": out[3]}
+
+    def download(self, want_info=True, allow_failed_windows=False):
+        W, N, S, B = self.W, self.N, self.S, self.B
+        models, pred, resid = np.empty((W, 4)), np.empty((W, N)), np.empty((W, N))
+        raw = np.empty((W, B, 7))
+        ia = np.zeros((W, S), dtype=FIT_INFO_DTYPE) if want_info else None
+        ib = np.zeros((W, B), dtype=FIT_INFO_DTYPE) if want_info else None
+        bs = np.full(W, -1, dtype=np.int32)
+        rc = self._L.abn_multi_download(self._h, _dp(models), _dp(pred), _dp(resid), _dp(raw),
+                                        None if ia is None else ia.ctypes.data,
+                                        None if ib is None else ib.ctypes.data,
+                                        bs.ctypes.data_as(C.POINTER(C.c_int32)))
+        if not (rc == 5 and allow_failed_windows):
+            self._check(rc)
+        return {"models": models, "pred": pred, "resid": resid, "raw": raw, "info_a": ia, "info_b": ib,
+                "best_start": bs}
+
+    def counters(self):
+        out = (C.c_int64 * 5)()
+        self._check(self._L.abn_multi_counters(self._h, out))
+        return {"fits": out[0], "evals": out[1], "iters": out[2], "evals_skipped": out[3] + out[4],
+                "evals_skipped_starts": out[3], "evals_skipped_boot": out[4]}

@@ -13,7 +13,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libabneutral_hip.so"
-SOURCES = [CSRC / "abn_api.hip"]
+SOURCES = [CSRC / "abn_api.hip", CSRC / "abn_multi.hip"]
 DEPS = [CSRC / "abn_device.hpp", CSRC / "abn_philox.h", PKG.parent / "include" / "abneutral.h"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
@@ -24,6 +24,7 @@ HIPCC_FLAGS = [
     "-fPIC",
     "-shared",
     "-Wall",
+    "-ldl",
 ]
 
 

@@ -210,11 +210,17 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
   if (chains <= 0) return ABN_OK;
   const int ng = kWave / lanes;
   int rmax = pick_rmax(a.N, lanes);
+  // the reduction tree: packed kernels sum in their own lanes; a wavefront per chain reproduces the pedigree's tree
+  if (lanes != kWave || a.tree <= 0 || a.tree > kWave) a.tree = lanes;
+  if (a.tree < kWave && (rmax <= 0 || rmax > 8 || (a.tree == 8 && a.N > 32)))
+    return set_err(c, ABN_ERR_INVALID_ARG, "internal: tree emulation needs a resident pedigree of at most 8 rows per lane");
   const int np = ((a.N + 1) & ~1) + ((a.K + 1) / 2);  // resident observations + this chain's triple list
   if (rmax > 0) {
     if ((size_t)ng * (size_t)(a.chain_stride + np) * sizeof(double) > kLdsResidentMax) rmax = 0;
     else a.chain_stride += np;
   }
+  if (rmax <= 0 && lanes == kWave && a.tree < kWave)
+    return set_err(c, ABN_ERR_INVALID_ARG, "internal: tree emulation needs a resident pedigree");
   // stream mode: rows shorter than one trip of the deep loop (kStreamBlocks x 4 rows x lanes) use the pair-loop variant
   if (rmax == 0 && a.N < 2 * kStreamBlocks * kStreamVec * lanes) rmax = -1;
   const size_t lds = (size_t)ng * (size_t)a.chain_stride * sizeof(double);
@@ -257,10 +263,22 @@ static long long spec_max_chains(int n_rows) {
   return pick_rmax(n_rows, kWave) <= 2 ? kPhaseASpecMax : kPhaseASpecMax * 2 / 3;
 }
 
+// a wavefront per chain can reproduce a tree of fewer accumulators (tree_sum64) for resident pedigrees of up to
+// eight rows per lane; the 8-accumulator tree only for the pedigrees it is chosen for (N <= 32)
+static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree) {
+  if (tree >= kWave) return true;
+  const int rmax = pick_rmax(n_rows, kWave);
+  if (rmax <= 0 || rmax > 8) return false;
+  if (tree == 8 && n_rows > 32) return false;
+  const int np = ((n_rows + 1) & ~1) + n_rows / 2 + 1;
+  return (size_t)(chain_stride + np) * sizeof(double) <= kLdsResidentMax;
+}
+
 static bool spec_applicable(const FitArgs& a) {
   if (a.dmode == 2) return false;  // resident observations only (starts, or bootstraps gathered through the index row)
   const int rmax = pick_rmax(a.N, kWave);
   if (rmax == 0 || rmax > 8) return false;  // 16 rows per lane: the plain resident kernel
+  if (!tree_on_wave_ok(a.N, a.chain_stride, a.tree)) return false;
   const int np = (a.N + 1) & ~1;
   return (3 * (size_t)(a.chain_stride + np) + kSpecCommDoubles) * sizeof(double) <= kLdsResidentMax;
 }
@@ -318,6 +336,23 @@ static const char* options_error(const abn_options& o) {
   if (o.stream_mode < 0 || o.stream_mode > 1) return "stream_mode must be 0 or 1";
   if (o.window_groups < 0) return "window_groups must be >= 0";
   return nullptr;
+}
+
+// The residual reduction tree of a pedigree (abn_options.lanes_per_chain; abn_fit_info.lanes): host arithmetic on
+// the topology alone — no device, no launch size.
+extern "C" int abn_reduction_tree(const abn_options* opts, const double* generations, int32_t n_rows, int32_t* tree) {
+  if (!generations || n_rows <= 0 || !tree) return ABN_ERR_INVALID_ARG;
+  const abn_options o = resolve(opts);
+  if (const char* oe = options_error(o)) {
+    (void)oe;
+    return ABN_ERR_INVALID_ARG;
+  }
+  Topology t;
+  const int rc = build_topology(generations, n_rows, 3, t);
+  if (rc) return rc;
+  const int lanes = pick_lanes(n_rows, o.lanes_per_chain, t.chain_stride);
+  *tree = fit_streams(n_rows, t.chain_stride, lanes) ? (lanes | ((kStreamVec - 1) << 8)) : lanes;
+  return ABN_OK;
 }
 
 extern "C" int abn_version(void) { return ABN_VERSION_MAJOR * 100 + ABN_VERSION_MINOR; }
@@ -427,12 +462,13 @@ extern "C" int abn_gen_boot_simplices(uint64_t seed, uint32_t window, uint32_t b
   return ABN_OK;
 }
 
-static int launch_gen_idx(abn_ctx* c, uint32_t* idx, int n, int b, int w, uint64_t seed, uint32_t woff, uint32_t boff) {
+static int launch_gen_idx(abn_ctx* c, uint32_t* idx, int n, int b, int w, uint64_t seed, uint32_t woff, uint32_t boff,
+                          const uint32_t* wid = nullptr) {
   const long long total = (long long)w * b * ((n + 3) / 4);
   if (total <= 0) return ABN_OK;
   const long long want = (total + 255) / 256;
   const unsigned blocks = (unsigned)std::min<long long>(want, 256LL * 32);
-  hipLaunchKernelGGL(abn_gen_idx_kernel, dim3(blocks), dim3(256), 0, c->stream, idx, n, b, w, seed, woff, boff);
+  hipLaunchKernelGGL(abn_gen_idx_kernel, dim3(blocks), dim3(256), 0, c->stream, idx, n, b, w, seed, woff, boff, wid);
   HIPCHK(c, hipGetLastError());
   return ABN_OK;
 }
@@ -624,6 +660,7 @@ extern "C" int abn_fit_batch(abn_ctx* c, const abn_options* opts, const double* 
   a.info = dinfo.p;
   a.raw = nullptr;
   const int lanes = pick_lanes(N, o.lanes_per_chain, t.chain_stride);
+  a.tree = lanes;
   rc = launch_fit(c, a, lanes, c->stream);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(best, dbest.p, dbest.bytes(), hipMemcpyDeviceToHost, c->stream));
@@ -642,8 +679,10 @@ struct abn_plan {
   DevTopology dtopo;
   int N = 0, W = 0, S = 0, B = 0;
   uint32_t window_offset = 0, boot_offset = 0;
-  int lanes = 16;    // phase B (throughput: many chains)
+  int lanes = 16;    // the pedigree's reduction tree = lanes per chain of the packed (throughput) kernels
   int lanes_a = 64;  // phase A (few chains: latency-bound, one wavefront per chain is fastest)
+  std::vector<uint32_t> wid_host;  // Philox window ids (abn_plan_set_window_ids); empty = window_offset + w
+  DevBuf<uint32_t> wid;
   bool windows_set = false, phase_a_done = false, ran_a = false, ran_b = false;
   DevBuf<double> D, pred, resid, p_uu, eqp, eqp_w, simplexA, bestA, model, lse, bestB, raw_own;
   DevBuf<FitInfoDev> infoA, infoB;
@@ -708,7 +747,11 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   // four-wavefront speculative kernel beats both (scripts/phase_a_sweep.py, C3 topology: 1000 chains 2.6 / 3.2 /
   // 4.6 ms for speculative / 64 lanes / 16 lanes, 1500 chains 4.2 / 3.4 / 4.8; 4000 chains - / 4.6 / 5.9 ms;
   // 8000 chains - / 7.7 / 7.0 ms)
-  if (p->opt.lanes_per_chain == 0 && (long long)n_windows * n_starts <= kPhaseAWideMax) p->lanes_a = 64;
+  // The reduction tree stays the pedigree's (p->lanes) whichever kernel runs: results do not depend on the size of
+  // the launch, hence not on how a job is sharded over GPUs.
+  if (p->opt.lanes_per_chain == 0 && (long long)n_windows * n_starts <= kPhaseAWideMax &&
+      tree_on_wave_ok(n_rows, p->topo.chain_stride, p->lanes))
+    p->lanes_a = 64;
   if ((size_t)(kWave / p->lanes) * p->topo.chain_stride * sizeof(double) > kMaxDynLds ||
       ((size_t)p->topo.chain_stride + kSelChunk) * sizeof(double) > kMaxDynLds) {
     delete p;
@@ -775,11 +818,28 @@ static int plan_upload_model(abn_plan* p, const double* model, const double* pre
   HIPCHK(c, hipMemcpyAsync(p->p_uu.p, p0uu, W * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(p->eqp.p, eqp, W * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(p->eqp_w.p, eqp_w, W * sizeof(double), hipMemcpyHostToDevice, c->stream));
-  int rc = launch_gen_idx(c, p->idx.p, p->N, p->B, p->W, p->opt.seed, p->window_offset, p->boot_offset);
+  int rc = launch_gen_idx(c, p->idx.p, p->N, p->B, p->W, p->opt.seed, p->window_offset, p->boot_offset, p->wid.p);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   p->windows_set = true;
   p->phase_a_done = true;
+  return ABN_OK;
+}
+
+extern "C" int abn_plan_set_window_ids(abn_plan* p, const uint32_t* ids) {
+  if (!p) return ABN_ERR_INVALID_ARG;
+  abn_ctx* c = p->ctx;
+  if (p->windows_set) return set_err(c, ABN_ERR_STATE, "abn_plan_set_window_ids must precede abn_plan_set_windows");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!ids) {
+    p->wid_host.clear();
+    p->wid.release();
+    return ABN_OK;
+  }
+  p->wid_host.assign(ids, ids + p->W);
+  HIPCHK(c, p->wid.alloc((size_t)p->W));
+  HIPCHK(c, hipMemcpyAsync(p->wid.p, p->wid_host.data(), p->wid.bytes(), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return ABN_OK;
 }
 
@@ -801,11 +861,12 @@ extern "C" int abn_plan_set_windows(abn_plan* p, const double* d_obs, const doub
   for (size_t w = 0; w < W; ++w) {
     double mx = d_obs[w * N];  // max of column 3, src/ab_neutral.rs:25-29
     for (size_t i = 1; i < N; ++i) mx = std::max(mx, d_obs[w * N + i]);
-    abn_gen_start_simplices(p->opt.seed, p->window_offset + (uint32_t)w, p->S, mx, sx.data() + w * S * 20);
+    const uint32_t wg = p->wid_host.empty() ? p->window_offset + (uint32_t)w : p->wid_host[w];
+    abn_gen_start_simplices(p->opt.seed, wg, p->S, mx, sx.data() + w * S * 20);
   }
   if (!sx.empty())
     HIPCHK(c, hipMemcpyAsync(p->simplexA.p, sx.data(), p->simplexA.bytes(), hipMemcpyHostToDevice, c->stream));
-  int rc = launch_gen_idx(c, p->idx.p, p->N, p->B, p->W, p->opt.seed, p->window_offset, p->boot_offset);
+  int rc = launch_gen_idx(c, p->idx.p, p->N, p->B, p->W, p->opt.seed, p->window_offset, p->boot_offset, p->wid.p);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));  // sx / ones are host temporaries
   p->windows_set = true;
@@ -833,6 +894,8 @@ static void fill_common(const abn_plan* p, FitArgs& a) {
   a.seed = p->opt.seed;
   a.window_offset = p->window_offset;
   a.boot_offset = p->boot_offset;
+  a.wid = p->wid.p;
+  a.tree = p->lanes;
   a.W = p->W;
   a.shrink_variant = p->opt.shrink_on_failed_contraction ? 1 : 0;
   a.no_skip = p->opt.no_fixed_point_skip ? 1 : 0;
@@ -852,6 +915,7 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   a.eqp_w += o;
   a.D += o * N;
   a.window_offset += (uint32_t)w0;
+  if (a.wid) a.wid += o;
   a.W = wn;
   a.dmode = 0;
   a.smode = 0;
@@ -931,6 +995,7 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   a.idx += o * B * N;
   a.model += o * 4;
   a.window_offset += (uint32_t)w0;
+  if (a.wid) a.wid += o;
   a.W = wn;
   a.dmode = 1;
   a.smode = 1;
@@ -1096,9 +1161,32 @@ extern "C" int abn_plan_download(abn_plan* p, double* models, double* pred, doub
   if (raw && B) HIPCHK(c, hipMemcpyAsync(raw, p->raw, W * B * 7 * sizeof(double), hipMemcpyDeviceToHost, s));
   if (info_a && p->S) HIPCHK(c, hipMemcpyAsync(info_a, p->infoA.p, p->infoA.bytes(), hipMemcpyDeviceToHost, s));
   if (info_b && B) HIPCHK(c, hipMemcpyAsync(info_b, p->infoB.p, p->infoB.bytes(), hipMemcpyDeviceToHost, s));
-  if (best_start)
-    HIPCHK(c, hipMemcpyAsync(best_start, p->best_start.p, p->best_start.bytes(), hipMemcpyDeviceToHost, s));
+  std::vector<int32_t> bs;
+  if (p->ran_a) {  // the selection's verdict per window, whether or not the caller asked for it
+    bs.resize(W);
+    HIPCHK(c, hipMemcpyAsync(bs.data(), p->best_start.p, p->best_start.bytes(), hipMemcpyDeviceToHost, s));
+  }
   HIPCHK(c, hipStreamSynchronize(s));
+  if (best_start) {
+    if (p->ran_a) std::copy(bs.begin(), bs.end(), best_start);
+    else std::fill(best_start, best_start + W, 0);  // model uploaded by the caller (abn_boot_model_run)
+  }
+  // every buffer has been filled; windows whose starts all ended non-finite carry NaN and best_start = -1
+  for (int32_t b : bs)
+    if (b < 0) return set_err(c, ABN_ERR_NO_FINITE_FIT, "a window has no finite start (best_start = -1): its rows are NaN");
+  return ABN_OK;
+}
+
+extern "C" int abn_plan_failed_windows(abn_plan* p, int32_t* n_failed) {
+  if (!p || !n_failed) return ABN_ERR_INVALID_ARG;
+  abn_ctx* c = p->ctx;
+  *n_failed = 0;
+  if (!p->ran_a) return ABN_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  std::vector<int32_t> bs((size_t)p->W);
+  HIPCHK(c, hipMemcpyAsync(bs.data(), p->best_start.p, p->best_start.bytes(), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int32_t b : bs) *n_failed += b < 0 ? 1 : 0;
   return ABN_OK;
 }
 
@@ -1199,7 +1287,14 @@ extern "C" int abn_ab_neutral_run(abn_ctx* c, const abn_options* opts, const dou
   rc = abn_plan_set_windows(p, d.data(), &p0uu, &eqp, &eqp_weight);
   if (!rc) rc = abn_plan_run_phase(p, 0);
   int32_t best = -1;
-  if (!rc) rc = abn_plan_download(p, model, pred, resid, nullptr, info, nullptr, &best);
+  bool no_fit = false;
+  if (!rc) {
+    rc = abn_plan_download(p, model, pred, resid, nullptr, info, nullptr, &best);
+    if (rc == ABN_ERR_NO_FINITE_FIT) {  // buffers are filled (NaN model); report after the optional outputs
+      no_fit = true;
+      rc = ABN_OK;
+    }
+  }
   if (!rc && all_models) {
     hipError_t e = hipMemcpy(all_models, p->bestA.p, p->bestA.bytes(), hipMemcpyDeviceToHost);
     if (e != hipSuccess) rc = set_err(c, ABN_ERR_HIP, hipGetErrorString(e));
@@ -1209,7 +1304,7 @@ extern "C" int abn_ab_neutral_run(abn_ctx* c, const abn_options* opts, const dou
     if (e != hipSuccess) rc = set_err(c, ABN_ERR_HIP, hipGetErrorString(e));
   }
   abn_plan_destroy(p);
-  if (!rc && best < 0) rc = set_err(c, ABN_ERR_NO_FINITE_FIT, abn_status_string(ABN_ERR_NO_FINITE_FIT));
+  if (!rc && (no_fit || best < 0)) rc = set_err(c, ABN_ERR_NO_FINITE_FIT, abn_status_string(ABN_ERR_NO_FINITE_FIT));
   return rc;
 }
 

@@ -81,6 +81,12 @@ struct FitArgs {
   const double* model;   // [W*4]
   uint64_t seed;
   uint32_t window_offset, boot_offset;
+  const uint32_t* wid;   // nullable [W]: the window's index in the Philox counters (default window_offset + w)
+  // Residual reduction tree (the oracle's `lanes`): a property of the PEDIGREE, not of the launch.  The packed
+  // kernels (G lanes per chain) need tree == G; the one-wavefront-per-chain kernels (abn_fit_kernel<64, RMAX > 0>,
+  // abn_fit_spec_kernel) reproduce the tree of 8, 16 or 32 accumulators bit for bit (tree_sum64), so that the
+  // kernel may be chosen by the size of the launch while the results stay those of the pedigree's tree.
+  int tree;
   // chains: W windows x C chains
   int W, C;
   int max_iters;
@@ -487,6 +493,79 @@ __device__ __forceinline__ double group_sum_dpp(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// The residual sum of a chain that owns a whole wavefront, in the value tree of `tree` accumulators.
+// Lane L holds t[q] = term of row L + 64 q (+0.0 for rows past the end).  tree == 64: every lane sums its own
+// rows, then the xor-butterfly over 64 lanes.  tree < 64 (the pedigree's packed kernels use that many lanes per
+// chain): accumulator l < tree sums rows l, l + tree, l + 2 tree, ... in that order — in this layout the values of
+// lanes l, l + tree, ... of q = 0, then of q = 1, ...  Lanes 0..tree-1 collect them with row rotations (DPP) and
+// v_permlane16/32_swap, add in exactly that order, and finish with the same xor-butterfly over `tree` lanes as
+// group_sum_dpp<tree>; the result is broadcast from lane 0.  acc starts at +0.0 and x + 0.0 == x bit for bit
+// (no term is -0.0), so skipped rows and all-zero segments leave the bits untouched.  All 64 lanes must be active.
+// ------------------------------------------------------------------------------------------------
+constexpr int kDppRowRor8 = 0x128;  // lane i <- lane (i + 8) & 15 inside each 16 lanes
+struct F64Pair {
+  double a, b;
+};
+// v_permlane16_swap with both operands = v: a = (r0, r0, r2, r2), b = (r1, r1, r3, r3) for v = rows (r0, r1, r2, r3)
+__device__ __forceinline__ F64Pair swap16_pair(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return {__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1])};
+}
+// v_permlane32_swap with both operands = v: a = (r0, r1, r0, r1), b = (r2, r3, r2, r3)
+__device__ __forceinline__ F64Pair swap32_pair(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return {__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1])};
+}
+__device__ __forceinline__ double wave_first(double v) {  // lane 0's value in every lane
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+template <int RMAX>
+__device__ __forceinline__ double tree_sum64(const double (&t)[RMAX], int tree) {
+  double acc = 0.0;
+  if (tree >= 64) {
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) acc = acc + t[q];
+    return group_sum_dpp<64>(acc);
+  }
+  if (tree == 32) {
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const F64Pair h = swap32_pair(t[q]);       // lanes 0..31: rows l + 64 q, then rows l + 32 + 64 q
+      acc = acc + h.a;
+      acc = acc + h.b;
+    }
+    acc = group_sum_dpp<32>(acc);
+  } else if (tree == 16) {
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const F64Pair s = swap16_pair(t[q]);       // row 0 of s.a / s.b: lanes 0..15 / 16..31 of t
+      const F64Pair u = swap32_pair(t[q]);       // row 0 of u.b: lanes 32..47
+      const F64Pair v = swap16_pair(u.b);        // row 0 of v.b: lanes 48..63
+      acc = acc + s.a;
+      acc = acc + s.b;
+      acc = acc + u.b;
+      acc = acc + v.b;
+    }
+    acc = group_sum_dpp<16>(acc);
+  } else {  // tree == 8: the host admits it for N <= 32 only (rows live in lanes 0..31 of q = 0; the rest is +0.0)
+    const F64Pair s = swap16_pair(t[0]);
+    acc = acc + t[0];                            // lanes 0..7
+    acc = acc + dpp_mov<kDppRowRor8>(t[0]);      // lanes 8..15
+    acc = acc + s.b;                             // lanes 16..23
+    acc = acc + dpp_mov<kDppRowRor8>(s.b);       // lanes 24..31
+    acc = group_sum_dpp<8>(acc);
+  }
+  return wave_first(acc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The fit kernel.  RMAX > 0 ("resident", needs N <= G*RMAX): the chain's observed divergences
 // (bootstrap: pred_i + resid[idx_i], gathered once per fit) are staged in LDS, each lane keeps its
 // triples and its rows' triple ids in registers; an evaluation touches no global memory.
@@ -569,7 +648,7 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
     for (int k = 0; k < 5; ++k) vx[k] = s0[4 * k + dim];
   } else {  // [params, vary() x4], src/boot_model.rs:69-75
     const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
-    const uint32_t wg = a.window_offset + (uint32_t)w, bg = a.boot_offset + (uint32_t)j;
+    const uint32_t wg = a.wid ? a.wid[w] : a.window_offset + (uint32_t)w, bg = a.boot_offset + (uint32_t)j;
     vx[0] = a.model[4 * w + dim];
 #pragma unroll
     for (int v = 1; v < 5; ++v) {
@@ -622,7 +701,27 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
     __syncthreads();
     ABN_STAMP(2);
     double acc = 0.0;                                        // P4
-    if (!STREAM) {
+    bool summed = false;
+    if constexpr (!STREAM && G == kWave && RR <= 8) {
+      if (a.tree < kWave) {                                  // the pedigree's tree has fewer accumulators than lanes
+        double dv[RR], tv[RR], term[RR];
+#pragma unroll
+        for (int q = 0; q < RR; ++q) {
+          const int i = gl + G * q;
+          dv[q] = dobs[i < N ? i : N - 1];
+          tv[q] = dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu];
+        }
+#pragma unroll
+        for (int q = 0; q < RR; ++q) {
+          const double r = dv[q] - ic - tv[q];
+          term[q] = ((gl + G * q) < N) ? (r * r + pen) : 0.0;
+        }
+        acc = tree_sum64<RR>(term, a.tree);                  // P4 + P5 in the tree's order
+        summed = true;
+      }
+    }
+    if (summed) {
+    } else if (!STREAM) {
       constexpr int RC = RR < 8 ? RR : 8;                    // eight rows per lane at a time
 #pragma unroll
       for (int q0 = 0; q0 < RR; q0 += RC) {
@@ -720,7 +819,7 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
       }
     }
     ABN_STAMP(3);
-    acc = group_sum_dpp<G>(acc);                             // P5
+    if (!summed) acc = group_sum_dpp<G>(acc);                // P5
     __syncthreads();
     ABN_STAMP(4);
     return acc;
@@ -924,7 +1023,7 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
       fo.iters = iter;
       fo.evals = evals;
       fo.status = fin_status;
-      fo.lanes = STREAM ? (G | ((kStreamVec - 1) << 8)) : G;  // reduction-tree code (oracle: `lanes`)
+      fo.lanes = STREAM ? (G | ((kStreamVec - 1) << 8)) : (G == kWave ? a.tree : G);  // reduction-tree code (oracle: `lanes`)
       a.info[chain] = fo;
     }
     if (a.raw) {
@@ -1026,7 +1125,7 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
       for (int k = 0; k < 5; ++k) vx[k] = s0[4 * k + dim];
     } else {  // [params, vary() x4], src/boot_model.rs:69-75
       const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
-      const uint32_t wg = a.window_offset + (uint32_t)w, bg = a.boot_offset + (uint32_t)j;
+      const uint32_t wg = a.wid ? a.wid[w] : a.window_offset + (uint32_t)w, bg = a.boot_offset + (uint32_t)j;
       vx[0] = a.model[4 * w + dim];
 #pragma unroll
       for (int v = 1; v < 5; ++v) {
@@ -1336,7 +1435,7 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
     } else {
       const int j = (int)(chain - (long long)w * a.C);
       const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
-      const uint32_t wg = a.window_offset + (uint32_t)w, bg = a.boot_offset + (uint32_t)j;
+      const uint32_t wg = a.wid ? a.wid[w] : a.window_offset + (uint32_t)w, bg = a.boot_offset + (uint32_t)j;
       vx[0] = a.model[4 * w + dim];
 #pragma unroll
       for (int v = 1; v < 5; ++v) {
@@ -1402,14 +1501,24 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
       dv[q] = in ? dobs[gl + G * q] : 0.0;
       tv[q] = in ? dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu] : 0.0;
     }
+    if (a.tree < kWave) {  // the pedigree's tree has fewer accumulators than lanes (FitArgs::tree)
+      double term[RMAX];
 #pragma unroll
-    for (int q = 0; q < RMAX; ++q) {
-      if ((gl + G * q) < N) {
+      for (int q = 0; q < RMAX; ++q) {
         const double r = dv[q] - ic - tv[q];
-        acc = acc + (r * r + pen);
+        term[q] = ((gl + G * q) < N) ? (r * r + pen) : 0.0;
       }
+      acc = tree_sum64<RMAX>(term, a.tree);
+    } else {
+#pragma unroll
+      for (int q = 0; q < RMAX; ++q) {
+        if ((gl + G * q) < N) {
+          const double r = dv[q] - ic - tv[q];
+          acc = acc + (r * r + pen);
+        }
+      }
+      acc = group_sum_dpp<G>(acc);
     }
-    acc = group_sum_dpp<G>(acc);
     wave_lds_fence();
     ABN_STAMP(3);
     return acc;
@@ -1754,7 +1863,7 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
       fo.iters = iter;
       fo.evals = evals;
       fo.status = have_best ? status : 2;
-      fo.lanes = G;
+      fo.lanes = a.tree;
       a.info[chain] = fo;
     }
     if (a.raw) {
@@ -2061,7 +2170,8 @@ __global__ __launch_bounds__(256) void abn_make_dstar_kernel(double* dstar, cons
 // call yields the indices of rows 4q..4q+3 of one bootstrap.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void abn_gen_idx_kernel(uint32_t* idx, int N, int B, int W, uint64_t seed,
-                                                          uint32_t window_offset, uint32_t boot_offset) {
+                                                          uint32_t window_offset, uint32_t boot_offset,
+                                                          const uint32_t* wid) {
   const int Q = (N + 3) / 4;
   const long long total = (long long)W * B * Q;
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
@@ -2072,7 +2182,7 @@ __global__ __launch_bounds__(256) void abn_gen_idx_kernel(uint32_t* idx, int N, 
     const int b = (int)(wb % B);
     const int w = (int)(wb / B);
     uint32_t r[4];
-    philox4x32_10((uint32_t)q, boot_offset + (uint32_t)b, window_offset + (uint32_t)w, kTagIdx, k0, k1, r);
+    philox4x32_10((uint32_t)q, boot_offset + (uint32_t)b, wid ? wid[w] : window_offset + (uint32_t)w, kTagIdx, k0, k1, r);
     uint32_t* row = idx + (size_t)wb * (size_t)N;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {

@@ -94,7 +94,7 @@ def hip_shard_runner(ctx, generations, d_obs, p0uu, n_starts, options=None):
     torch tensor (no copy before the RCCL gather)."""
     import torch
 
-    from . import Plan
+    from . import AbnError, Plan
 
     d_obs = np.asarray(d_obs, dtype=np.float64)
     p0uu = np.asarray(p0uu, dtype=np.float64)
@@ -110,7 +110,10 @@ def hip_shard_runner(ctx, generations, d_obs, p0uu, n_starts, options=None):
         plan.set_windows(d_obs[w0:w0 + wn], p0uu[w0:w0 + wn])
         plan.run()
         plan.sync()
+        failed = plan.failed_windows()
         plan.close()
+        if failed:  # the reference panics (src/ab_neutral.rs:28,100); never gather NaN tables silently
+            raise AbnError(5, f"{failed} window(s) of the shard [{w0}, {w0 + wn}) have no finite start")
         return raw
 
     return run

@@ -112,16 +112,21 @@ inline Output alphabeta_multiple(const WindowArgs& args, uint32_t max_gene_lengt
       p0uu[w] = wins[members[w]].p0uu;
     }
     abn_plan* plan = nullptr;
-    // window_offset: the first member's position, so that every window draws from its own Philox streams
     dev.check(abn_plan_create(dev.get(), &dev.options, gens.data(), (int32_t)N, (int32_t)W, (int32_t)S, (int32_t)B,
                               (uint32_t)wins[members[0]].index, 0, &plan),
               "abn_plan_create");
+    // every window draws from the Philox streams of ITS position in the (region, window) enumeration, whatever
+    // windows failed before it and whichever topology group it landed in
+    std::vector<uint32_t> ids(W);
+    for (size_t w = 0; w < W; ++w) ids[w] = (uint32_t)wins[members[w]].index;
     std::vector<double> mod(W * 4), raw(W * B * 7);
     std::vector<int32_t> best(W);
-    int rc = abn_plan_set_windows(plan, D.data(), p0uu.data(), nullptr, nullptr);
+    int rc = abn_plan_set_window_ids(plan, ids.data());
+    if (!rc) rc = abn_plan_set_windows(plan, D.data(), p0uu.data(), nullptr, nullptr);
     if (!rc) rc = abn_plan_run(plan);
     if (!rc) rc = abn_plan_download(plan, mod.data(), nullptr, nullptr, raw.data(), nullptr, nullptr, best.data());
     abn_plan_destroy(plan);
+    if (rc == ABN_ERR_NO_FINITE_FIT) rc = ABN_OK;  // per window below: best[w] < 0 is printed and skipped (:64-65)
     dev.check(rc, "metaprofile plan");
     for (size_t w = 0; w < W; ++w) {
       const size_t i = members[w];

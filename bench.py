@@ -116,16 +116,19 @@ def cpu_baseline(wl, model, pred, resid, lanes, seed, evals_per_fit, budget_s=12
                               threads=cores)
         return time.perf_counter() - t0, float(res["evals"].sum())
 
-    nb, iters = cores, 4                                # probe: 5 + <= 8 evaluations per fit and thread
+    nb_next, it_next = cores, 4                         # probe: 5 + <= 8 evaluations per fit and thread
     for _ in range(5):
+        nb, iters = nb_next, it_next                    # (nb, iters) always belong to the run that gave (dt, ev)
         dt, ev = run(nb, iters, False)
         if dt >= 0.75 * budget_s:
             break
         target = ev / dt * budget_s                     # evaluations the budget buys at the measured rate
         if target >= 4.0 * cores * evals_per_fit:       # whole fits: >= 4 per thread
-            nb, iters = int(min(8192.0 * cores, target / evals_per_fit)), 1000
+            nb_next, it_next = int(min(8192.0 * cores, target / evals_per_fit)), 1000
         else:                                           # truncated fits, one per thread
-            nb, iters = cores, max(4, int(target / cores / 1.7) - 5)
+            nb_next, it_next = cores, max(4, int(target / cores / 1.7) - 5)
+        if (nb_next, it_next) == (nb, iters):
+            break
     dt_t, ev_t = run(nb, iters, True)
     whole = iters == 1000
     fits = nb / dt if whole else ev / dt / evals_per_fit
@@ -142,14 +145,89 @@ def cpu_baseline(wl, model, pred, resid, lanes, seed, evals_per_fit, budget_s=12
     }
 
 
-def stream_probe(A, ctx, seed, steps=2):
+def kernel_source_sha1() -> str:
+    """content hash of the device/host sources of libabneutral_hip.so: a PMC traffic figure is only quoted for
+    the kernels it was measured on"""
+    import hashlib
+
+    h = hashlib.sha1()
+    for f in sorted((ROOT / "alphabeta_rs_amd" / "csrc").glob("*")):
+        if f.suffix in {".hip", ".hpp", ".h"}:
+            h.update(f.name.encode())
+            h.update(f.read_bytes())
+    return h.hexdigest()
+
+
+def measured_traffic(workload: str):
+    """HBM bytes per phase-B launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_fit_boot_<wl>.json,
+    written by scripts/profile_round.sh) — used only when that profile was taken on the kernel sources of this very
+    build; a stale profile yields null and says so."""
+    sha = kernel_source_sha1()
+    cands = sorted((ROOT / "profiles").glob(f"r*_pmc_fit_boot_{workload}.json"), reverse=True)
+    for f in cands:
+        try:
+            j = json.loads(f.read_text())
+        except Exception:
+            continue
+        if j.get("workload") == workload and j.get("source_sha1") == sha:
+            return j.get("hbm_bytes_per_launch"), {"file": f"profiles/{f.name}", "source_sha1": sha,
+                                                   "kernel": j.get("kernel"), "collected": j.get("collected")}
+    return None, {"note": "no rocprofv3 PMC profile of this build's kernel sources under profiles/ "
+                          f"(source_sha1 {sha[:12]}); run scripts/profile_round.sh", "source_sha1": sha}
+
+
+def pcie_inclusive(A, ctx, wl, opts, reps=5):
+    """The drop-in entry points on HOST buffers (abn_ab_neutral_run + abn_boot_model_run: allocation, H2D, start
+    simplices, index generation, kernels, D2H) for a one-window workload: fits/s including PCIe."""
+    ped = np.concatenate([wl["gens"], wl["D"][0][:, None]], axis=1)
+    p0 = float(wl["p0"][0])
+    S, B = wl["S"], wl["B"]
+
+    def once():
+        model, pred, resid, _ = ctx.ab_neutral_run(ped, p0, p0, 1.0, S, options=opts)
+        ctx.boot_model_run(ped, model, pred, resid, p0, p0, 1.0, B, options=opts)
+
+    once()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    dt = (time.perf_counter() - t0) / reps
+    return {"fits_per_s": (S + B) / dt, "ms_per_step": 1e3 * dt, "reps": reps,
+            "what": "abn_ab_neutral_run + abn_boot_model_run on host buffers, end to end"}
+
+
+def quick_workload(A, ctx, name, seed, steps=3):
+    """a few steps of another BASELINE configuration on this GPU, so that its number is driver-run too"""
+    wl = make_workload(name, 0, 1)
+    plan = A.Plan(ctx, wl["gens"], wl["wr"], wl["S"], wl["B"], options=A.default_options(seed=seed))
+    plan.set_windows(wl["D"], wl["p0"])
+    plan.run()
+    plan.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run()
+    plan.sync()
+    dt = (time.perf_counter() - t0) / steps
+    cnt = plan.counters()
+    kms = plan.kernel_ms()
+    plan.close()
+    return {"workload": wl["label"], "fits_per_s": cnt["fits"] / dt, "ms_per_step": 1e3 * dt, "steps": steps,
+            "candidate_evals_per_s": (cnt["evals"] - cnt["evals_skipped"]) / dt, "kernel_ms": kms}
+
+
+def stream_probe(A, ctx, seed, steps=2, every=5, B=8192, tag="C5 shard"):
     """Short run of the HBM-facing configuration (a C5 shard, stream mode: the bootstrap observations of a fit
-    are re-read from HBM on every evaluation) so that the bench line also carries the roofline of the kernel
-    variant the HBM roof actually applies to.  Phase B only is timed (HIP events on the launch stream)."""
+    are re-read on every evaluation) so that the bench line also carries the roofline of the kernel variant the
+    HBM roof actually applies to.  Phase B only is timed (HIP events on the launch stream).
+
+    What the rate is a rate OF: the kernel streams 8N+40 B per evaluation from beyond L2.  The 256 MiB Infinity
+    Cache (MALL) sits between L2 and DRAM, and the co-resident working set (co-resident chains x 8N bytes) decides
+    how much of that stream it can serve; `beyond_l2_*` is therefore an L2-miss rate (fabric traffic), equal to the
+    DRAM rate only when the working set is far above 256 MiB (--stream-sweep measures both ends)."""
     from alphabeta_rs_amd import synthetic
 
-    ped, p = synthetic.c5_pedigree()
-    N, B = ped.shape[0], 8192
+    ped, p = synthetic.c5_pedigree(every=every)
+    N = ped.shape[0]
     plan = A.Plan(ctx, ped[:, :3], 1, 2, B, options=A.default_options(seed=seed))
     plan.set_windows(ped[:, 3][None, :], np.array([p]))
     plan.run()
@@ -161,16 +239,70 @@ def stream_probe(A, ctx, seed, steps=2):
     out = plan.download()
     evals_b = int(out["info_b"]["evals"].sum()) - plan.counters()["evals_skipped_boot"]  # evaluations executed
     lanes = int(out["info_b"]["lanes"][0, 0])
+    K = len({tuple(r) for r in ped[:, :3].astype(int).tolist()})
     plan.close()
+    # co-resident chains: one wavefront per chain, limited by LDS (9(T+1) + K + 4 doubles per chain) and by the
+    # kernel's two wavefronts per SIMD
+    lds_chain = (9 * 126 + ((K + 1) & ~1) + 4) * 8
+    per_cu = max(1, min(8, (160 * 1024) // lds_chain))
+    resident = min(B, 256 * per_cu)
     alg = evals_b * (4 * N + 40) + B * 112 + N * 18
     streamed = evals_b * (8 * N + 40) + B * (12 * N + 112)
     achieved = alg / (ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None, "kernel": f"abn_fit_kernel<G={lanes & 0xff}, stream> phase B (+ abn_make_dstar_kernel)",
             "kernel_ms": ms, "algorithmic_bytes_per_launch": alg, "streamed_bytes_per_launch": streamed,
-            "streamed_GBps": streamed / (ms * 1e-3) / 1e9, "streamed_frac": streamed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "workload": f"C5 shard: N={N} rows, T=125, K=950, {B} bootstraps, {evals_b} evaluations; `achieved` at "
-                        "SURVEY's 4N+40 B per evaluation, `streamed_*` at the 8N+40 B the kernel streams from HBM"}
+            "beyond_l2_GBps": streamed / (ms * 1e-3) / 1e9,
+            "beyond_l2_frac_of_hbm_peak": streamed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "coresident_chains": resident, "coresident_working_set_MiB": resident * 8 * N / 2**20,
+            "infinity_cache_MiB": 256,
+            "workload": f"{tag}: N={N} rows, T=125, K={K}, {B} bootstraps, {evals_b} evaluations; `achieved` at "
+                        "SURVEY's 4N+40 B per evaluation; `beyond_l2_*` = the 8N+40 B per evaluation the kernel "
+                        "streams past L2 (HBM + Infinity Cache hits: a working set below ~256 MiB can be served "
+                        "partly by the Infinity Cache, so only the large-working-set figure is a DRAM rate)"}
+
+
+def stream_sweep(A, ctx, seed):
+    """the stream kernel with a co-resident working set far below and far above the Infinity Cache"""
+    return {"small_working_set": stream_probe(A, ctx, seed, steps=2, every=5, B=512, tag="C5 shard, 512 chains"),
+            "large_working_set": stream_probe(A, ctx, seed, steps=1, every=2, B=1024,
+                                              tag="deep pedigree sampled every 2nd generation")}
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: one child process per GPU (fresh interpreters, started
+    before this process initialises HIP; torch.cuda.device_count() does not), RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*
+    in their environment, rank 0's JSON line passed through.  Fails loudly when the node has fewer GPUs than asked for
+    (--backend gloo may oversubscribe one GPU to rehearse the multi-rank path)."""
+    import socket
+    import subprocess
+
+    import torch
+
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and args.backend == "nccl":
+        print(f"bench.py: --gpus {args.gpus} asked for but only {ndev} GPU(s) are visible: no number is reported "
+              "(RCCL needs one GPU per rank)", file=sys.stderr)
+        return 2
+    if ndev < 1:
+        print("bench.py needs an MI355X: the ABneutral path has no CPU fallback", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [pr.wait() for pr in procs[1:]]
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return next(c for c in codes if c) or 1
+    sys.stdout.write(out0)
+    return 0
 
 
 def main():
@@ -188,16 +320,28 @@ def main():
                     help="skip the short C5-shard run that measures the stream-mode kernel against the HBM roof")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 ranks on one GPU)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the short extra workloads (C2, C4 shard, G351) and the PCIe-inclusive timing")
+    ap.add_argument("--stream-sweep", action="store_true",
+                    help="also run the stream-mode kernel with a co-resident working set far below / far above the "
+                         "256 MiB Infinity Cache (slow to set up: a 123k-row pedigree)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher: start the ranks ourselves, BEFORE anything in this process touches the GPU
+        raise SystemExit(launch_ranks(args))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for a "
+                         "different GPU count than asked for")
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the ABneutral path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -310,26 +454,19 @@ def main():
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         flops_eval = 45 * T + 53 * K + 4 * N + 60
         valu_tflops = evals_b * flops_eval / kern_s / 1e12 if kern_s > 0 else 0.0
-        traffic = None
-        pmc = ROOT / "profiles" / f"r01_pmc_fit_boot_{args.workload}.json"
-        if pmc.exists():
-            try:
-                j = json.loads(pmc.read_text())
-                if j.get("workload") == args.workload:
-                    traffic = j.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic, traffic_source = measured_traffic(args.workload)
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
             "kernel": f"abn_fit_kernel<G={lanes}> phase B", "kernel_ms": kms["fit_boot"],
             "algorithmic_bytes_per_launch": alg_bytes,
             "mode": "stream" if stream else "resident",
             **({"streamed_bytes_per_launch": streamed_bytes,
-                "streamed_GBps": streamed_bytes / kern_s / 1e9,
-                "streamed_frac": streamed_bytes / kern_s / 1e9 / HBM_PEAK_GBS} if stream else {}),
+                "beyond_l2_GBps": streamed_bytes / kern_s / 1e9,
+                "beyond_l2_frac_of_hbm_peak": streamed_bytes / kern_s / 1e9 / HBM_PEAK_GBS} if stream else {}),
             "note": ("stream mode: `achieved` prices an evaluation at SURVEY's 4N+40 B (index stream); the kernel "
-                     "streams the materialised observations, 8N+40 B per evaluation from HBM: streamed_*" if stream
+                     "streams the materialised observations, 8N+40 B per evaluation past L2 (HBM + Infinity Cache): "
+                     "beyond_l2_*" if stream
                      else "LDS-resident fits: the index row is read once per fit, so the HBM roofline is nominal; "
                           "the kernel is FP64-VALU/latency bound (see valu_fp64)"),
             "valu_fp64": {"achieved_tflops": valu_tflops, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
@@ -352,6 +489,13 @@ def main():
         }
         if world == 1 and not args.no_stream_probe and args.workload != "c5s":
             result["roofline_stream"] = stream_probe(A, ctx, seed)
+            if args.stream_sweep:
+                result["roofline_stream_sweep"] = stream_sweep(A, ctx, seed)
+        if world == 1 and not args.no_extras:
+            if Wr == 1:
+                result["pcie_inclusive"] = pcie_inclusive(A, ctx, wl, opts)
+            result["extra_workloads"] = {n: quick_workload(A, ctx, n, seed) for n in ("c2", "c4", "g351")
+                                         if n != args.workload}
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a one-GPU (rank 0) measurement
             bs = int(out["best_start"][0])
             if bs >= 0:

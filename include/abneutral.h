@@ -49,7 +49,12 @@ typedef struct abn_plan abn_plan;
 
 typedef struct abn_options {
   uint64_t seed;                        /* Philox4x32-10 key (reference: unseeded thread_rng)           */
-  int32_t lanes_per_chain;              /* 0 = auto; 8, 16, 32 or 64 lanes of a wavefront per chain    */
+  int32_t lanes_per_chain;              /* 0 = auto; 8, 16, 32 or 64: accumulators of the residual reduction
+                                           tree = lanes per chain of the packed kernels.  Auto picks it from the
+                                           PEDIGREE alone (rows, generations, distinct triples) — never from the
+                                           number of fits in the launch — so results are independent of batch size
+                                           and of how a job is sharded over GPUs; few-chain launches use one (or
+                                           four) wavefronts per chain and reproduce the same tree bit for bit     */
   int32_t strict_order;                 /* abn_cost_batch: 1 = serial row-order sum (reference order)  */
   int32_t shrink_on_failed_contraction; /* 0 = argmin 0.8.1 behaviour; 1 = textbook Nelder-Mead        */
   int32_t max_iters_start;              /* 10000, src/ab_neutral.rs:62                                 */
@@ -76,7 +81,7 @@ typedef struct abn_fit_info {
   int32_t iters;    /* next_iter() calls                                                                */
   int32_t evals;    /* cost() calls                                                                     */
   int32_t status;   /* ABN_FIT_*                                                                        */
-  int32_t lanes;    /* lanes per chain the kernel used (defines the residual reduction tree)            */
+  int32_t lanes;    /* residual reduction tree (accumulators; | rows-per-block code << 8 in stream mode) */
 } abn_fit_info;
 
 /* ------------------------------------------------------------------ context */
@@ -91,6 +96,10 @@ int abn_shutdown(abn_ctx* ctx);
 const char* abn_last_error(const abn_ctx* ctx);
 const char* abn_status_string(int status);
 int abn_version(void);
+
+/* The residual reduction tree the fits of this pedigree use (what abn_fit_info.lanes reports): a function of the
+ * pedigree's generations (N x 3) and opts->lanes_per_chain only — host arithmetic, no device needed. */
+int abn_reduction_tree(const abn_options* opts, const double* generations, int32_t n_rows, int32_t* tree);
 
 /* ------------------------------------------------------------------ (1) cost function
  * Replaces `Problem::cost` (src/structs.rs:194-216) + `divergence()` (src/divergence.rs:33-94) for M
@@ -178,6 +187,11 @@ int abn_plan_create(abn_ctx* ctx, const abn_options* opts, const double* generat
                     int32_t n_rows, int32_t n_windows, int32_t n_starts, int32_t n_boot,
                     uint32_t window_offset, uint32_t boot_offset, abn_plan** plan);
 int abn_plan_destroy(abn_plan* plan);
+/* Optional, before abn_plan_set_windows: ids[W] = each window's index in the Philox counters (start simplices,
+ * jitter, bootstrap indices).  Default: window_offset + w.  The metaprofile driver passes every window's own
+ * position in the (region, window) enumeration (src/cli/metaprofile.rs:50-53), so that skipped windows and
+ * several topology groups never make two windows share a random stream.  NULL restores the default. */
+int abn_plan_set_window_ids(abn_plan* plan, const uint32_t* ids);
 /* D[W x N], p0uu[W]; eqp = p0uu and eqp_weight = 1 as src/alphabeta.rs:33-54 unless eqp/eqp_weight
  * are non-NULL ([W] each).  Also draws the start simplices and generates the bootstrap index buffer
  * idx[W x B x N] (u32) in HBM on the device. */
@@ -194,15 +208,57 @@ int abn_plan_kernel_ms(abn_plan* plan, double* ms3);
 int abn_plan_raw_device_ptr(abn_plan* plan, void** dev_ptr);
 int abn_plan_bind_raw(abn_plan* plan, void* dev_ptr);
 /* copy results to the host; any pointer may be NULL.  models[W x 4], pred[W x N], resid[W x N],
- * raw[W x B x 7], info_a[W x S], info_b[W x B], best_start[W] (int32, -1 = ABN_ERR_NO_FINITE_FIT) */
+ * raw[W x B x 7], info_a[W x S], info_b[W x B], best_start[W] (int32, -1 = no start of that window ended finite).
+ * Returns ABN_ERR_NO_FINITE_FIT — AFTER filling every buffer — when any window has best_start = -1 (the reference
+ * panics, src/ab_neutral.rs:28,100; metaprofile prints and skips the window, src/cli/metaprofile.rs:64-65): that
+ * window's model, pred, resid and bootstrap rows are NaN, the other windows are valid. */
 int abn_plan_download(abn_plan* plan, double* models, double* pred, double* resid, double* raw,
                       abn_fit_info* info_a, abn_fit_info* info_b, int32_t* best_start);
+/* number of windows whose selection found no finite start in the last phase-A run (cheap: W int32 come back) */
+int abn_plan_failed_windows(abn_plan* plan, int32_t* n_failed);
 /* sums over all fits of the last run (for evals/s): out[0] = fits, out[1] = evals (cost() calls of the reference
  * algorithm = sum of abn_fit_info.evals), out[2] = iters, out[3] / out[4] = evaluations of out[1] in the start / bootstrap
  * fits that were NOT executed because the fit had reached a fixed point (options.no_fixed_point_skip) */
 int abn_plan_counters(abn_plan* plan, int64_t* out5);
 /* number of bytes of device memory the plan holds (index buffer included) */
 int abn_plan_device_bytes(abn_plan* plan, int64_t* bytes);
+
+/* ------------------------------------------------------------------ (5) one process, several GPUs of a node
+ * The metaprofile loop (src/cli/metaprofile.rs:50-72) over all MI355X of a node from ONE host thread: a plan per
+ * device on a stream of its own (the devices run concurrently), windows dealt in contiguous blocks — or, with fewer
+ * windows than devices, every device repeats the cheap phase A (same inputs, same bits) and takes a contiguous slice
+ * of the bootstraps.  Every fit is independent and every random draw is a function of the GLOBAL (window,
+ * bootstrap) index, and the reduction tree is the pedigree's (abn_options.lanes_per_chain): the tables are
+ * byte-identical for every number of devices.  abn_multi_run ends with the one exchange step of the path: the
+ * gather of the bootstrap tables (56 B per fit) into every device's copy of raw[W x B x 7] over xGMI with RCCL
+ * (in-place ncclAllGather for equal window blocks, else ncclBroadcast per block), enqueued behind the kernels on
+ * each device's stream.  RCCL is bound at run time (librccl.so.1) and only when n_devices > 1.
+ * devices[n_devices]: distinct HIP ordinals.  On failure *out may be non-NULL (abn_multi_last_error explains it)
+ * and must still be destroyed. */
+typedef struct abn_multi abn_multi;
+int abn_multi_create(const int32_t* devices, int32_t n_devices, const abn_options* opts,
+                     const double* generations /* N x 3 */, int32_t n_rows, int32_t n_windows, int32_t n_starts,
+                     int32_t n_boot, abn_multi** out);
+int abn_multi_destroy(abn_multi* m);
+const char* abn_multi_last_error(const abn_multi* m);
+/* D[W x N], p0uu[W], optional eqp[W], eqp_weight[W] for ALL windows (as abn_plan_set_windows) */
+int abn_multi_set_windows(abn_multi* m, const double* d_obs, const double* p0uu, const double* eqp,
+                          const double* eqp_weight);
+/* A -> select -> B on every device, then the gather; asynchronous */
+int abn_multi_run(abn_multi* m);
+int abn_multi_sync(abn_multi* m);
+/* out4 = window_offset, n_windows, boot_offset, n_boot of the shard of devices[device_index] */
+int abn_multi_shard(abn_multi* m, int32_t device_index, int32_t* out4);
+/* the gathered table raw[W x B x 7] in the memory of devices[device_index] (valid after abn_multi_sync) */
+int abn_multi_raw_device_ptr(abn_multi* m, int32_t device_index, void** dev_ptr);
+/* as abn_plan_download for all W windows (raw comes from the first device's gathered table); returns
+ * ABN_ERR_NO_FINITE_FIT after filling every buffer when a window has no finite start */
+int abn_multi_download(abn_multi* m, double* models, double* pred, double* resid, double* raw,
+                       abn_fit_info* info_a, abn_fit_info* info_b, int32_t* best_start);
+/* abn_plan_counters summed over the devices (bootstrap-sharded mode: the replicated phase-A fits count per device) */
+int abn_multi_counters(abn_multi* m, int64_t* out5);
+/* *ok = 1 when librccl.so.1 can be loaded and exports every symbol the gather uses */
+int abn_multi_rccl_available(int* ok);
 
 #ifdef __cplusplus
 }

@@ -50,8 +50,18 @@ if big:
         hbm = (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
         summary["phase_b_kernel"] = b
         summary["hbm_bytes_per_launch"] = hbm
+        import datetime
+        import hashlib
+
+        h = hashlib.sha1()  # the same content hash bench.py computes: the figure belongs to these kernel sources
+        root = Path(sys.argv[4]) if len(sys.argv) > 4 else out.parent
+        for f in sorted((root / "alphabeta_rs_amd" / "csrc").glob("*")):
+            if f.suffix in {".hip", ".hpp", ".h"}:
+                h.update(f.name.encode())
+                h.update(f.read_bytes())
         (out / f"{tag.split('_')[0]}_pmc_fit_boot_{workload}.json").write_text(json.dumps(
             {"workload": workload, "kernel": b, "FETCH_SIZE_KiB": p["FETCH_SIZE"], "WRITE_SIZE_KiB": p["WRITE_SIZE"],
-             "hbm_bytes_per_launch": hbm}, indent=1))
+             "hbm_bytes_per_launch": hbm, "source_sha1": h.hexdigest(),
+             "collected": datetime.date.today().isoformat()}, indent=1))
 (out / f"{tag}_rocprof_summary.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps(summary, indent=1))

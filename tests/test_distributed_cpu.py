@@ -21,16 +21,21 @@ def _free_port():
 
 
 def _oracle_tables(ped_gens, D, p0, S, seed, w0, wn, b0, bn):
+    """the oracle standing in for one rank's plan.  The reduction tree is what the product reports for this pedigree
+    under AUTO options (abn_reduction_tree: host arithmetic on the generations alone, so it cannot depend on the
+    size of a rank's shard) — the GPU counterpart is tests/test_gpu_parity.py::test_results_do_not_depend_on_launch_size"""
+    import alphabeta_rs_amd as A
     import oracle as O
 
+    lanes = A.reduction_tree(ped_gens)
     out = np.empty((wn, bn, 7))
     for i in range(wn):
         w = w0 + i
         ped = np.concatenate([ped_gens, D[w][:, None]], axis=1)
         s0 = np.stack([O.start_simplex(seed, w, s, D[w].max()) for s in range(S)])
-        fits = O.fit_batch(ped, p0[w], p0[w], 1.0, s0, 10000, lanes=16, threads=1)
+        fits = O.fit_batch(ped, p0[w], p0[w], 1.0, s0, 10000, lanes=lanes, threads=1)
         k, model, pred, resid, _ = O.select_best(ped, p0[w], fits["best"])
-        raw, _ = O.boot_model(ped, model, pred, resid, p0[w], p0[w], 1.0, seed, w, b0, bn, lanes=16, threads=1)
+        raw, _ = O.boot_model(ped, model, pred, resid, p0[w], p0[w], 1.0, seed, w, b0, bn, lanes=lanes, threads=1)
         out[i] = raw
     return out
 
@@ -63,21 +68,52 @@ def _worker(rank, world, port, W, B, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("W,B,mode", [(3, 5, "windows"), (1, 7, "bootstraps"), (2, 4, "windows")])
-def test_two_rank_gloo_shard_and_gather(W, B, mode):
+@pytest.mark.parametrize("world,W,B,mode", [(2, 3, 5, "windows"), (2, 1, 7, "bootstraps"), (2, 2, 4, "windows"),
+                                            (8, 9, 3, "windows"), (8, 2, 11, "bootstraps")])
+def test_gloo_shard_and_gather_matches_unsharded(world, W, B, mode):
+    """world 2 and 8 (ragged shards included) against the unsharded (world 1) table, bit for bit"""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, W, B, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, W, B, q)) for r in range(world)]
     for p in procs:
         p.start()
-    ok, got_mode, shape = q.get(timeout=120)
+    ok, got_mode, shape = q.get(timeout=300)
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     assert ok and got_mode == mode and shape == (W, B, 7)
+
+
+def test_reduction_tree_is_a_function_of_the_pedigree_only(abn):
+    """abn_reduction_tree takes generations and options — no fit counts: the tree cannot change with sharding.
+    C3's topology -> 16 accumulators, the bundled pedigree -> 8, the 351-row golden one -> 64."""
+    import oracle as O
+    from alphabeta_rs_amd import synthetic
+
+    assert abn.reduction_tree(synthetic.c3_pedigree()[0][:, :3]) == 16
+    assert abn.reduction_tree(O.load_pedigree(ROOT / "tests" / "golden" / "pedigree_generated.txt")[:, :3]) == 8
+    assert abn.reduction_tree(O.load_pedigree(ROOT / "tests" / "golden" / "pedigree.txt")[:, :3]) == 64
+    assert abn.reduction_tree(synthetic.c3_pedigree()[0][:, :3], abn.default_options(lanes_per_chain=32)) == 32
+
+
+def test_bench_refuses_a_gpu_count_it_cannot_run():
+    """`python bench.py --gpus 2` on a box without two GPUs exits non-zero and prints no JSON line (round 1 printed
+    n_gpus = 1); a WORLD_SIZE that contradicts --gpus is refused as well."""
+    import subprocess
+
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")},
+                       timeout=300)
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "{" not in r.stdout
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "1"], capture_output=True, text=True,
+                       env=dict(os.environ, WORLD_SIZE="2", RANK="0"), timeout=300)
+    assert r.returncode != 0 and "{" not in r.stdout and "WORLD_SIZE" in r.stderr
 
 
 def test_shard_ranges_cover_everything():
