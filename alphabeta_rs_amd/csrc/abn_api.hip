@@ -212,8 +212,8 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
   int rmax = pick_rmax(a.N, lanes);
   // the reduction tree: packed kernels sum in their own lanes; a wavefront per chain reproduces the pedigree's tree
   if (lanes != kWave || a.tree <= 0 || a.tree > kWave) a.tree = lanes;
-  if (a.tree < kWave && (rmax <= 0 || rmax > 8 || (a.tree == 8 && a.N > 32)))
-    return set_err(c, ABN_ERR_INVALID_ARG, "internal: tree emulation needs a resident pedigree of at most 8 rows per lane");
+  if (lanes == kWave && a.tree < kWave && (rmax <= 0 || rmax > 8 || a.N > a.tree * kPackedRowsMax))
+    return set_err(c, ABN_ERR_INVALID_ARG, "internal: a wavefront per chain reproduces a smaller tree for resident pedigrees of at most 8 rows per accumulator only");
   const int np = ((a.N + 1) & ~1) + ((a.K + 1) / 2);  // resident observations + this chain's triple list
   if (rmax > 0) {
     if ((size_t)ng * (size_t)(a.chain_stride + np) * sizeof(double) > kLdsResidentMax) rmax = 0;
@@ -263,13 +263,13 @@ static long long spec_max_chains(int n_rows) {
   return pick_rmax(n_rows, kWave) <= 2 ? kPhaseASpecMax : kPhaseASpecMax * 2 / 3;
 }
 
-// a wavefront per chain can reproduce a tree of fewer accumulators (tree_sum64) for resident pedigrees of up to
-// eight rows per lane; the 8-accumulator tree only for the pedigrees it is chosen for (N <= 32)
+// a wavefront per chain can reproduce a tree of fewer accumulators (packed_tree_sum) for LDS-resident pedigrees of
+// up to eight rows per accumulator — every pedigree the auto rule gives such a tree
 static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree) {
   if (tree >= kWave) return true;
   const int rmax = pick_rmax(n_rows, kWave);
   if (rmax <= 0 || rmax > 8) return false;
-  if (tree == 8 && n_rows > 32) return false;
+  if (n_rows > tree * kPackedRowsMax) return false;
   const int np = ((n_rows + 1) & ~1) + n_rows / 2 + 1;
   return (size_t)(chain_stride + np) * sizeof(double) <= kLdsResidentMax;
 }
@@ -279,6 +279,10 @@ static bool spec_applicable(const FitArgs& a) {
   const int rmax = pick_rmax(a.N, kWave);
   if (rmax == 0 || rmax > 8) return false;  // 16 rows per lane: the plain resident kernel
   if (!tree_on_wave_ok(a.N, a.chain_stride, a.tree)) return false;
+  if (a.tree > 0 && a.tree < kWave) {  // the instantiated (rows per lane, rows per accumulator) pairs of launch_fit_spec
+    const int nq = packed_rows_bound(a.N, a.tree);
+    if (rmax == 8 || (rmax == 4 && nq < 4) || (rmax == 2 && nq < 2)) return false;
+  }
   const int np = (a.N + 1) & ~1;
   return (3 * (size_t)(a.chain_stride + np) + kSpecCommDoubles) * sizeof(double) <= kLdsResidentMax;
 }
@@ -290,12 +294,32 @@ static int launch_fit_spec(abn_ctx* c, FitArgs a, hipStream_t st) {
   a.chain_stride += (a.N + 1) & ~1;
   const size_t lds = (3 * (size_t)a.chain_stride + kSpecCommDoubles) * sizeof(double);
   dim3 grid((unsigned)chains), block(4 * kWave);
-  switch (rmax) {
-    case 1: hipLaunchKernelGGL(abn_fit_spec_kernel<1>, grid, block, lds, st, a); break;
-    case 2: hipLaunchKernelGGL(abn_fit_spec_kernel<2>, grid, block, lds, st, a); break;
-    case 4: hipLaunchKernelGGL(abn_fit_spec_kernel<4>, grid, block, lds, st, a); break;
-    default: hipLaunchKernelGGL(abn_fit_spec_kernel<8>, grid, block, lds, st, a); break;
+  if (a.tree <= 0 || a.tree > kWave) a.tree = kWave;
+#define ABN_SPEC(R, Q) hipLaunchKernelGGL((abn_fit_spec_kernel<R, Q>), grid, block, lds, st, a)
+  if (a.tree < kWave) {  // the pedigree's tree has fewer accumulators than a wavefront has lanes: (rows per lane at 64
+    const int nq = packed_rows_bound(a.N, a.tree);  // lanes, rows per accumulator) — the combinations spec_applicable admits
+    const int key = rmax * 16 + nq;
+    switch (key) {
+      case 1 * 16 + 1: ABN_SPEC(1, 1); break;
+      case 1 * 16 + 2: ABN_SPEC(1, 2); break;
+      case 1 * 16 + 4: ABN_SPEC(1, 4); break;
+      case 1 * 16 + 8: ABN_SPEC(1, 8); break;
+      case 2 * 16 + 2: ABN_SPEC(2, 2); break;
+      case 2 * 16 + 4: ABN_SPEC(2, 4); break;
+      case 2 * 16 + 8: ABN_SPEC(2, 8); break;
+      case 4 * 16 + 4: ABN_SPEC(4, 4); break;
+      case 4 * 16 + 8: ABN_SPEC(4, 8); break;
+      default: return set_err(c, ABN_ERR_INVALID_ARG, "internal: no speculative kernel for this (rows, tree)");
+    }
+  } else {
+    switch (rmax) {
+      case 1: ABN_SPEC(1, 0); break;
+      case 2: ABN_SPEC(2, 0); break;
+      case 4: ABN_SPEC(4, 0); break;
+      default: ABN_SPEC(8, 0); break;
+    }
   }
+#undef ABN_SPEC
   HIPCHK(c, hipGetLastError());
   return ABN_OK;
 }

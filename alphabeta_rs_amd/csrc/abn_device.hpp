@@ -84,7 +84,7 @@ struct FitArgs {
   const uint32_t* wid;   // nullable [W]: the window's index in the Philox counters (default window_offset + w)
   // Residual reduction tree (the oracle's `lanes`): a property of the PEDIGREE, not of the launch.  The packed
   // kernels (G lanes per chain) need tree == G; the one-wavefront-per-chain kernels (abn_fit_kernel<64, RMAX > 0>,
-  // abn_fit_spec_kernel) reproduce the tree of 8, 16 or 32 accumulators bit for bit (tree_sum64), so that the
+  // abn_fit_spec_kernel) reproduce the tree of 8, 16 or 32 accumulators bit for bit (packed_tree_sum), so that the
   // kernel may be chosen by the size of the launch while the results stay those of the pedigree's tree.
   int tree;
   // chains: W windows x C chains
@@ -493,76 +493,72 @@ __device__ __forceinline__ double group_sum_dpp(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The residual sum of a chain that owns a whole wavefront, in the value tree of `tree` accumulators.
-// Lane L holds t[q] = term of row L + 64 q (+0.0 for rows past the end).  tree == 64: every lane sums its own
-// rows, then the xor-butterfly over 64 lanes.  tree < 64 (the pedigree's packed kernels use that many lanes per
-// chain): accumulator l < tree sums rows l, l + tree, l + 2 tree, ... in that order — in this layout the values of
-// lanes l, l + tree, ... of q = 0, then of q = 1, ...  Lanes 0..tree-1 collect them with row rotations (DPP) and
-// v_permlane16/32_swap, add in exactly that order, and finish with the same xor-butterfly over `tree` lanes as
-// group_sum_dpp<tree>; the result is broadcast from lane 0.  acc starts at +0.0 and x + 0.0 == x bit for bit
-// (no term is -0.0), so skipped rows and all-zero segments leave the bits untouched.  All 64 lanes must be active.
+// P4 + P5 of a chain that owns a whole wavefront, in the value tree of a pedigree whose packed kernels give a chain
+// `tree` < 64 lanes (FitArgs::tree).  The wavefront simply does what the packed kernel's group does, in 64/tree
+// identical copies: lane L works as accumulator l = L & (tree - 1) and sums rows l, l + tree, l + 2 tree, ...
+// (at most eight, the packed kernels' limit) in that order, then the xor-butterfly over `tree` lanes runs inside
+// every group of `tree` lanes at once — all 64 lanes end with the same bits as group_sum_dpp<tree> of the packed
+// kernel (lanes of different copies read the same LDS addresses: broadcasts, no bank conflicts).  Measured against
+// collecting a 64-lane layout's terms with v_permlane swaps (12 swaps + 8 dependent adds for 105 rows): the C3 phase
+// A went 1.14 -> 1.31 ms that way; the replicated form adds only the extra rows' arithmetic.
+// tq: this lane's row -> triple ids (element offsets into dt), two per register, for rows l + tree q.
 // ------------------------------------------------------------------------------------------------
-constexpr int kDppRowRor8 = 0x128;  // lane i <- lane (i + 8) & 15 inside each 16 lanes
-struct F64Pair {
-  double a, b;
-};
-// v_permlane16_swap with both operands = v: a = (r0, r0, r2, r2), b = (r1, r1, r3, r3) for v = rows (r0, r1, r2, r3)
-__device__ __forceinline__ F64Pair swap16_pair(double v) {
-  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-  const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  return {__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1])};
-}
-// v_permlane32_swap with both operands = v: a = (r0, r1, r0, r1), b = (r2, r3, r2, r3)
-__device__ __forceinline__ F64Pair swap32_pair(double v) {
-  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-  const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return {__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1])};
-}
-__device__ __forceinline__ double wave_first(double v) {  // lane 0's value in every lane
-  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-  return __hiloint2double(hi, lo);
+constexpr int kPackedRowsMax = 8;
+
+__device__ __forceinline__ void packed_row_ids(uint32_t (&tq)[kPackedRowsMax / 2], const uint16_t* tid, int N, int tree,
+                                               int lane) {
+  const int l = lane & (tree - 1);
+#pragma unroll
+  for (int q = 0; q < kPackedRowsMax / 2; ++q) tq[q] = 0u;
+#pragma unroll
+  for (int q = 0; q < kPackedRowsMax; ++q) {
+    const int i = l + tree * q;
+    if (i < N) tq[q / 2] |= (uint32_t)tid[i] << (16 * (q & 1));
+  }
 }
 
-template <int RMAX>
-__device__ __forceinline__ double tree_sum64(const double (&t)[RMAX], int tree) {
+// NQ: compile-time bound of the rows per accumulator, ceil(N / tree) rounded up to a power of two (rows past the end
+// read row N-1 and add +0.0): straight-line code, all LDS reads first, then the arithmetic.
+template <int NQ>
+__device__ __forceinline__ double packed_tree_sum(const uint32_t (&tq)[kPackedRowsMax / 2], const double* dobs,
+                                                  const double* dtab, double ic, double pen, int N, int tree, int lane) {
+  static_assert(NQ >= 1 && NQ <= kPackedRowsMax, "rows per accumulator");
+  const int l = lane & (tree - 1);
+  double dv[NQ], tv[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int i = l + tree * q;
+    dv[q] = dobs[i < N ? i : N - 1];
+    tv[q] = dtab[(tq[q / 2] >> (16 * (q & 1))) & 0xffffu];
+  }
   double acc = 0.0;
-  if (tree >= 64) {
 #pragma unroll
-    for (int q = 0; q < RMAX; ++q) acc = acc + t[q];
-    return group_sum_dpp<64>(acc);
+  for (int q = 0; q < NQ; ++q) {
+    const double r = dv[q] - ic - tv[q];
+    const double term = r * r + pen;
+    acc = acc + (((l + tree * q) < N) ? term : 0.0);  // x + 0.0 == x bit for bit (acc is never -0.0)
   }
-  if (tree == 32) {
-#pragma unroll
-    for (int q = 0; q < RMAX; ++q) {
-      const F64Pair h = swap32_pair(t[q]);       // lanes 0..31: rows l + 64 q, then rows l + 32 + 64 q
-      acc = acc + h.a;
-      acc = acc + h.b;
-    }
-    acc = group_sum_dpp<32>(acc);
-  } else if (tree == 16) {
-#pragma unroll
-    for (int q = 0; q < RMAX; ++q) {
-      const F64Pair s = swap16_pair(t[q]);       // row 0 of s.a / s.b: lanes 0..15 / 16..31 of t
-      const F64Pair u = swap32_pair(t[q]);       // row 0 of u.b: lanes 32..47
-      const F64Pair v = swap16_pair(u.b);        // row 0 of v.b: lanes 48..63
-      acc = acc + s.a;
-      acc = acc + s.b;
-      acc = acc + u.b;
-      acc = acc + v.b;
-    }
-    acc = group_sum_dpp<16>(acc);
-  } else {  // tree == 8: the host admits it for N <= 32 only (rows live in lanes 0..31 of q = 0; the rest is +0.0)
-    const F64Pair s = swap16_pair(t[0]);
-    acc = acc + t[0];                            // lanes 0..7
-    acc = acc + dpp_mov<kDppRowRor8>(t[0]);      // lanes 8..15
-    acc = acc + s.b;                             // lanes 16..23
-    acc = acc + dpp_mov<kDppRowRor8>(s.b);       // lanes 24..31
-    acc = group_sum_dpp<8>(acc);
+  acc = acc + dpp_mov<kDppQuadXor1>(acc);
+  acc = acc + dpp_mov<kDppQuadXor2>(acc);
+  acc = acc + dpp_mov<kDppRowHalfMirror>(acc);
+  if (tree >= 16) acc = acc + dpp_mov<kDppRowMirror>(acc);
+  if (tree >= 32) acc = swap_sum<16>(acc);
+  return acc;
+}
+// host and device agree on the bound: 1, 2, 4 or 8
+__host__ __device__ inline int packed_rows_bound(int n_rows, int tree) {
+  const int nq = (n_rows + tree - 1) / tree;
+  return nq <= 1 ? 1 : (nq <= 2 ? 2 : (nq <= 4 ? 4 : 8));
+}
+__device__ __forceinline__ double packed_tree_sum_any(const uint32_t (&tq)[kPackedRowsMax / 2], const double* dobs,
+                                                      const double* dtab, double ic, double pen, int N, int tree,
+                                                      int lane) {
+  switch (packed_rows_bound(N, tree)) {  // uniform
+    case 1: return packed_tree_sum<1>(tq, dobs, dtab, ic, pen, N, tree, lane);
+    case 2: return packed_tree_sum<2>(tq, dobs, dtab, ic, pen, N, tree, lane);
+    case 4: return packed_tree_sum<4>(tq, dobs, dtab, ic, pen, N, tree, lane);
+    default: return packed_tree_sum<8>(tq, dobs, dtab, ic, pen, N, tree, lane);
   }
-  return wave_first(acc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -622,21 +618,29 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
   }
   // ---- resident mode: observed divergences staged in LDS once per fit (bootstrap: gathered through the
   // index row); this lane's triples and row->triple ids (as LDS byte offsets into dt) in registers
-  uint32_t tidp[(RR + 1) / 2];  // two 16-bit triple ids per register
+  // two 16-bit triple ids per register: rows gl + G q — or, for a wavefront per chain that reproduces a tree of fewer
+  // accumulators (FitArgs::tree < 64, uniform per launch), rows (gl & (tree - 1)) + tree q of packed_tree_sum
+  constexpr bool MAYPACK = !STREAM && G == kWave && RR <= 8;
+  constexpr int NTID = MAYPACK ? kPackedRowsMax / 2 : (RR + 1) / 2;
+  uint32_t tidp[NTID];
+  const bool packed = MAYPACK && a.tree < kWave;
   uint32_t* tri_s = reinterpret_cast<uint32_t*>(dobs + ((N + 1) & ~1));  // this chain's copy of the triple list
   if (!STREAM) {
     for (int t = gl; t < K; t += G) tri_s[t] = a.tri[t];
 #pragma unroll
-    for (int q = 0; q < (RR + 1) / 2; ++q) tidp[q] = 0u;
+    for (int q = 0; q < NTID; ++q) tidp[q] = 0u;
 #pragma unroll
     for (int q = 0; q < RR; ++q) {
       const int i = gl + G * q;
       if (i < N) {
-        tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
+        if (!packed) tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
         dobs[i] = (a.dmode == 1) ? a.pred[wN + i] + a.resid[wN + idx_row[i]]  // src/boot_model.rs:50-54
                                  : a.D[dN + i];
       }
     }
+  }
+  if constexpr (MAYPACK) {
+    if (packed) packed_row_ids(tidp, a.tid, N, a.tree, lane);
   }
   __syncthreads();
 
@@ -702,21 +706,9 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
     ABN_STAMP(2);
     double acc = 0.0;                                        // P4
     bool summed = false;
-    if constexpr (!STREAM && G == kWave && RR <= 8) {
-      if (a.tree < kWave) {                                  // the pedigree's tree has fewer accumulators than lanes
-        double dv[RR], tv[RR], term[RR];
-#pragma unroll
-        for (int q = 0; q < RR; ++q) {
-          const int i = gl + G * q;
-          dv[q] = dobs[i < N ? i : N - 1];
-          tv[q] = dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu];
-        }
-#pragma unroll
-        for (int q = 0; q < RR; ++q) {
-          const double r = dv[q] - ic - tv[q];
-          term[q] = ((gl + G * q) < N) ? (r * r + pen) : 0.0;
-        }
-        acc = tree_sum64<RR>(term, a.tree);                  // P4 + P5 in the tree's order
+    if constexpr (MAYPACK) {
+      if (packed) {                                          // the pedigree's tree has fewer accumulators than lanes
+        acc = packed_tree_sum_any(tidp, dobs, dtab, ic, pen, N, a.tree, lane);  // P4 + P5 as the packed kernels' groups
         summed = true;
       }
     }
@@ -1376,8 +1368,12 @@ constexpr int kSpecPreDoubles = kSpecOutcomes * 3 * 12;             // [outcome]
 constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16 + 2 * kSpecPreDoubles + 16;  // cost exchange, two candidate
                                                  // tables, shrink points, two tables of prepared inputs, two control blocks
 
-template <int RMAX>
+// NQ > 0: the pedigree's tree has fewer than 64 accumulators (FitArgs::tree) and at most NQ rows per accumulator
+// (packed_tree_sum<NQ>) — a template parameter so that the two row layouts never compete for registers (the kernel
+// sits at its VGPR limit: three workgroups per CU) and P4 is straight-line code.  NQ = 0: 64 accumulators.
+template <int RMAX, int NQ>
 __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_kernel(const FitArgs a) {
+  constexpr bool PACKED = NQ > 0;
   constexpr int G = kWave;
   extern __shared__ __align__(16) double lds[];
   const int wv = threadIdx.x >> 6;      // 0: reflection, 1: expansion, 2: contraction, 3: keeper
@@ -1399,11 +1395,15 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
 
   const int wi = w * a.wstride;
   const size_t wN = (size_t)w * (size_t)N;
-  uint32_t triv[RMAX], tidp[(RMAX + 1) / 2];
+  constexpr int NTID = PACKED ? kPackedRowsMax / 2 : (RMAX + 1) / 2;
+  uint32_t triv[RMAX], tidp[NTID];  // row -> triple ids of this lane's rows: gl + 64 q, or (PACKED) (gl & (tree-1)) + tree q
 #pragma unroll
-  for (int q = 0; q < (RMAX + 1) / 2; ++q) tidp[q] = 0u;
+  for (int q = 0; q < NTID; ++q) tidp[q] = 0u;
 #pragma unroll
   for (int q = 0; q < RMAX; ++q) triv[q] = 0u;
+  if constexpr (PACKED) {
+    if (!keeper) packed_row_ids(tidp, a.tid, N, a.tree, gl);
+  }
   // keeper state: the simplex, this lane's dimension of the five vertices in rank order
   double vx[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   if (!keeper) {
@@ -1420,7 +1420,7 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
       const int i = gl + G * q;
       triv[q] = (i < K) ? a.tri[i] : 0u;
       if (i < N) {
-        tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
+        if constexpr (!PACKED) tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
         dobs[i] = (a.dmode == 1) ? a.pred[wN + i] + a.resid[wN + idx_row[i]]  // src/boot_model.rs:50-54
                                  : a.D[wN + i];
       }
@@ -1494,22 +1494,16 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
     wave_lds_fence();
     ABN_STAMP(2);
     double acc = 0.0;
-    double dv[RMAX], tv[RMAX];
-#pragma unroll
-    for (int q = 0; q < RMAX; ++q) {
-      const bool in = (gl + G * q) < N;
-      dv[q] = in ? dobs[gl + G * q] : 0.0;
-      tv[q] = in ? dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu] : 0.0;
-    }
-    if (a.tree < kWave) {  // the pedigree's tree has fewer accumulators than lanes (FitArgs::tree)
-      double term[RMAX];
+    if constexpr (PACKED) {  // the pedigree's tree has fewer accumulators than lanes (FitArgs::tree)
+      acc = packed_tree_sum<(NQ > 0 ? NQ : 1)>(tidp, dobs, dtab, ic, pen, N, a.tree, gl);
+    } else {
+      double dv[RMAX], tv[RMAX];
 #pragma unroll
       for (int q = 0; q < RMAX; ++q) {
-        const double r = dv[q] - ic - tv[q];
-        term[q] = ((gl + G * q) < N) ? (r * r + pen) : 0.0;
+        const bool in = (gl + G * q) < N;
+        dv[q] = in ? dobs[gl + G * q] : 0.0;
+        tv[q] = in ? dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu] : 0.0;
       }
-      acc = tree_sum64<RMAX>(term, a.tree);
-    } else {
 #pragma unroll
       for (int q = 0; q < RMAX; ++q) {
         if ((gl + G * q) < N) {
