@@ -49,7 +49,7 @@ EXPORTED_SYMBOLS = [
     "abn_plan_set_window_ids", "abn_plan_failed_windows",
     "abn_multi_create", "abn_multi_destroy", "abn_multi_last_error", "abn_multi_set_windows", "abn_multi_run",
     "abn_multi_sync", "abn_multi_shard", "abn_multi_raw_device_ptr", "abn_multi_download", "abn_multi_counters",
-    "abn_multi_rccl_available", "abn_reduction_tree",
+    "abn_multi_rccl_available", "abn_reduction_tree", "abn_pairwise_divergence_dev",
 ]
 
 
@@ -118,6 +118,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     L.abn_bootstrap_rows.argtypes = [vp, dp, C.c_int64, dp]
     L.abn_pairwise_divergence.argtypes = [vp, C.POINTER(C.c_uint8), C.c_int32, C.c_int64, C.POINTER(C.c_uint64),
                                           C.POINTER(C.c_uint64), dp]
+    L.abn_pairwise_divergence_dev.argtypes = [vp, vp, C.c_int32, C.c_int64, vp, vp, vp, dp]
     L.abn_plan_create.argtypes = [vp, op, dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32,
                                   C.POINTER(vp)]
     L.abn_plan_destroy.argtypes = [vp]
@@ -335,6 +336,16 @@ class Context:
                                                     diff.ctypes.data_as(C.POINTER(C.c_uint64)),
                                                     both.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(dval)))
         return diff, both, dval
+
+    def pairwise_divergence_dev(self, codes_ptr: int, n_samples: int, n_sites: int, diff_ptr: int = 0,
+                                both_ptr: int = 0, dvalue_ptr: int = 0) -> float:
+        """The same on device-resident buffers (raw device pointers, e.g. torch tensors' data_ptr()): u8 codes
+        [n x L] in, u64 diff / both and f64 dvalue [pairs] out (0 = not wanted).  Returns the kernels' HIP-event ms."""
+        ms = C.c_double(0.0)
+        self._check(self._L.abn_pairwise_divergence_dev(self._h, C.c_void_p(codes_ptr), n_samples, n_sites,
+                                                        C.c_void_p(diff_ptr or None), C.c_void_p(both_ptr or None),
+                                                        C.c_void_p(dvalue_ptr or None), C.byref(ms)))
+        return ms.value
 
     # ---- (3) boot_model::run
     def boot_model_run(self, pedigree, model, pred, resid, p0uu, eqp, eqp_weight, n_boot, *,

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -1438,45 +1439,158 @@ extern "C" int abn_bootstrap_rows(abn_ctx* c, const double* best, int64_t n_boot
 // ------------------------------------------------------------------------------------------------
 // pedigree construction: pairwise divergence (src/pedigree.rs:210-261)
 // ------------------------------------------------------------------------------------------------
+// launch configuration of abn_pairwise_bits_kernel for n samples
+struct PairPlan {
+  PairArgs a{};
+  size_t lds = 0;
+  unsigned grid = 0;
+  int rows = 0;  // rows of `partial`
+  int bs = 2;    // samples per block
+  std::vector<uint32_t> item_tab;
+};
+
+static int plan_pairwise(abn_ctx* c, int n, long long L, PairPlan& pp) {
+  PairArgs& a = pp.a;
+  if (n > 65535) return set_err(c, ABN_ERR_INVALID_ARG, "too many samples");
+  a.n = n;
+  a.L = L;
+  a.npairs = n * (n - 1) / 2;
+  // samples per block: 4 x 4 pairs per unit halve the LDS traffic per instruction but need enough samples to keep 256
+  // threads busy (n = 15: ten 4 x 4 blocks against thirty-six 2 x 2 blocks)
+  int bs = n >= 32 ? 4 : 2;
+  if (const char* e = getenv("ABN_PAIR_BLOCK")) bs = atoi(e) == 4 ? 4 : 2;  // measurement aid
+  pp.bs = bs;
+  a.nb = (n + bs - 1) / bs;
+  a.items = a.nb * (a.nb + 1) / 2;
+  a.red_in_lds = a.npairs <= kPairLdsRedMax ? 1 : 0;
+  const size_t red_bytes = a.red_in_lds ? (size_t)a.npairs * sizeof(unsigned long long) + 8 : 0;
+  // tile: the largest power-of-two number of 32-site words per sample (<= 256) whose three planes fit ~40 KiB of LDS
+  // next to the per-pair sums, so that four workgroups share a CU's 160 KiB ...
+  int wt = 256;
+  auto bytes = [&](int w) { return (size_t)3 * a.nb * (bs * w + 4) * sizeof(uint32_t) + red_bytes; };
+  while (wt > 4 && bytes(wt) > 40 * 1024) wt >>= 1;
+  if (bytes(wt) > 64 * 1024) return set_err(c, ABN_ERR_INVALID_ARG, "too many samples for one LDS tile");
+  // ... and small enough that every workgroup sees a few tiles
+  while (wt > 32 && (L + 32ll * wt - 1) / (32ll * wt) < 256LL * 4) wt >>= 1;
+  a.WT = wt;
+  pp.lds = bytes(wt);
+  // work units = pair blocks x slices of a tile's words (slices are multiples of four words): enough units that the
+  // round-robin over 256 threads wastes little (>= 90 % of the thread-passes busy), as few slices as that takes
+  const int smax = wt / 4;
+  int S = 1;
+  for (int s = 1; s <= smax; s *= 2) {
+    const long long units = (long long)a.items * s;
+    const long long passes = (units + kPairThreads - 1) / kPairThreads;
+    S = s;
+    // every unit ends with one LDS atomic per pair: stop at the first slicing that keeps 70 % of the thread-passes busy
+    if ((double)units / (double)(passes * kPairThreads) >= 0.7) break;
+  }
+  if (const char* e = getenv("ABN_PAIR_SLICES")) {  // measurement aid
+    const int sl = atoi(e);
+    if (sl >= 1 && sl <= smax && (wt / 4) % sl == 0) S = sl;
+  }
+  if (const char* e = getenv("ABN_PAIR_DEBUG")) a.dbg = atoi(e);
+  a.S = S;
+  a.units = a.items * S;
+  a.ntiles = (L + 32ll * wt - 1) / (32ll * wt);
+  const long long per_cu = std::max<long long>(1, std::min<long long>((160 * 1024) / (long long)pp.lds, bs == 4 ? 3 : 4));
+  long long cu_blocks = per_cu;
+  if (const char* e = getenv("ABN_PAIR_GRID")) cu_blocks = std::max(1, atoi(e));  // measurement aid
+  pp.grid = (unsigned)std::max<long long>(1, std::min<long long>(a.ntiles, 256LL * cu_blocks));  // persistent workgroups
+  pp.rows = a.red_in_lds ? (int)pp.grid : 1;
+  pp.item_tab.clear();
+  pp.item_tab.reserve((size_t)a.items);
+  for (int I = 0; I < a.nb; ++I)
+    for (int J = I; J < a.nb; ++J) pp.item_tab.push_back((uint32_t)(bs * I) | ((uint32_t)(bs * J) << 16));
+  return ABN_OK;
+}
+
+// codes already on the device; outputs on the device (any may be null)
+static int pairwise_on_device(abn_ctx* c, const uint8_t* dcodes, int n, long long L, unsigned long long* ddiff,
+                              unsigned long long* dboth, double* ddval, double* kernel_ms) {
+  PairPlan pp;
+  int rc = plan_pairwise(c, n, L, pp);
+  if (rc) return rc;
+  pp.a.codes = dcodes;
+  DevBuf<unsigned long long> partial;
+  DevBuf<uint32_t> tab;
+  const size_t cols = (size_t)2 * pp.a.npairs;
+  HIPCHK(c, partial.alloc((size_t)pp.rows * cols));
+  HIPCHK(c, tab.alloc(pp.item_tab.size()));
+  if (!pp.a.red_in_lds) HIPCHK(c, hipMemsetAsync(partial.p, 0, partial.bytes(), c->stream));  // else every row is written
+  HIPCHK(c, hipMemcpyAsync(tab.p, pp.item_tab.data(), tab.bytes(), hipMemcpyHostToDevice, c->stream));
+  pp.a.partial = partial.p;
+  pp.a.item_tab = tab.p;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (kernel_ms) {
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+  }
+  if (L > 0) {
+    if (pp.bs == 4) {
+      if (pp.lds > 48 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(abn_pairwise_bits_kernel<4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.lds));
+      hipLaunchKernelGGL(abn_pairwise_bits_kernel<4>, dim3(pp.grid), dim3(kPairThreads), pp.lds, c->stream, pp.a);
+    } else {
+      if (pp.lds > 48 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(abn_pairwise_bits_kernel<2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.lds));
+      hipLaunchKernelGGL(abn_pairwise_bits_kernel<2>, dim3(pp.grid), dim3(kPairThreads), pp.lds, c->stream, pp.a);
+    }
+    HIPCHK(c, hipGetLastError());
+  }
+  // (no sites: zero rows are summed and every pair is 0 / 0)
+  hipLaunchKernelGGL(abn_pairwise_reduce_kernel, dim3((unsigned)((cols + kPairReduceCols - 1) / kPairReduceCols)),
+                     dim3(kPairReduceCols * kPairReduceGroups), 0, c->stream, partial.p, L > 0 ? pp.rows : 0, (int)cols,
+                     ddiff, dboth, ddval);
+  HIPCHK(c, hipGetLastError());
+  if (kernel_ms) {
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    *kernel_ms = ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // partial / tab (and the host table) are freed on return
+  return ABN_OK;
+}
+
+extern "C" int abn_pairwise_divergence_dev(abn_ctx* c, const void* dev_codes, int32_t n_samples, int64_t n_sites,
+                                           void* dev_diff, void* dev_both, void* dev_dvalue, double* kernel_ms) {
+  if (!c) return ABN_ERR_INVALID_ARG;
+  if (!dev_codes || n_samples <= 0 || n_sites < 0) return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
+  if (n_samples < 2) return ABN_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  return pairwise_on_device(c, (const uint8_t*)dev_codes, n_samples, n_sites, (unsigned long long*)dev_diff,
+                            (unsigned long long*)dev_both, (double*)dev_dvalue, kernel_ms);
+}
+
 extern "C" int abn_pairwise_divergence(abn_ctx* c, const uint8_t* codes, int32_t n_samples, int64_t n_sites,
                                        uint64_t* diff, uint64_t* both, double* dvalue) {
   if (!c) return ABN_ERR_INVALID_ARG;
   if (!codes || n_samples <= 0 || n_sites < 0) return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
   const size_t n = (size_t)n_samples, npairs = n * (n - 1) / 2;
   if (npairs == 0) return ABN_OK;
-  // tile: as many sites as fit 128 KiB of LDS for all samples, a multiple of 64, at most kPairTileMax
-  int tile_sites = (int)std::min<size_t>((size_t)kPairTileMax, ((size_t)128 * 1024 / n) & ~(size_t)63);
-  if (tile_sites < 64) return set_err(c, ABN_ERR_INVALID_ARG, "too many samples for one LDS tile (max 2048)");
   HIPCHK(c, hipSetDevice(c->device));
   DevBuf<uint8_t> dcodes;
   DevBuf<unsigned long long> ddiff, dboth;
+  DevBuf<double> ddv;
   HIPCHK(c, dcodes.alloc(std::max<size_t>(n * (size_t)n_sites, 4)));
   HIPCHK(c, ddiff.alloc(npairs));
   HIPCHK(c, dboth.alloc(npairs));
+  HIPCHK(c, ddv.alloc(npairs));
   if (n_sites > 0)
     HIPCHK(c, hipMemcpyAsync(dcodes.p, codes, n * (size_t)n_sites, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemsetAsync(ddiff.p, 0, ddiff.bytes(), c->stream));
-  HIPCHK(c, hipMemsetAsync(dboth.p, 0, dboth.bytes(), c->stream));
-  if (n_sites > 0) {
-    const size_t lds = n * (size_t)tile_sites;
-    if (lds > 64 * 1024)
-      HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(abn_pairwise_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const long long ntiles = ((long long)n_sites + tile_sites - 1) / tile_sites;
-    const unsigned blocks = (unsigned)std::min<long long>(ntiles, 256LL * 4);
-    hipLaunchKernelGGL(abn_pairwise_kernel, dim3(blocks), dim3(256), lds, c->stream, dcodes.p, n_samples,
-                       (long long)n_sites, tile_sites, ddiff.p, dboth.p);
-    HIPCHK(c, hipGetLastError());
-  }
-  std::vector<unsigned long long> hd(npairs), hb(npairs);
-  HIPCHK(c, hipMemcpyAsync(hd.data(), ddiff.p, ddiff.bytes(), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(hb.data(), dboth.p, dboth.bytes(), hipMemcpyDeviceToHost, c->stream));
+  int rc = pairwise_on_device(c, dcodes.p, n_samples, n_sites, ddiff.p, dboth.p, ddv.p, nullptr);
+  if (rc) return rc;
+  if (diff) HIPCHK(c, hipMemcpyAsync(diff, ddiff.p, ddiff.bytes(), hipMemcpyDeviceToHost, c->stream));
+  if (both) HIPCHK(c, hipMemcpyAsync(both, dboth.p, dboth.bytes(), hipMemcpyDeviceToHost, c->stream));
+  if (dvalue) HIPCHK(c, hipMemcpyAsync(dvalue, ddv.p, ddv.bytes(), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  for (size_t p = 0; p < npairs; ++p) {
-    if (diff) diff[p] = hd[p];
-    if (both) both[p] = hb[p];
-    if (dvalue) dvalue[p] = (double)hd[p] / (2.0 * (double)hb[p]);  // src/pedigree.rs:257
-  }
   return ABN_OK;
 }
 

@@ -215,6 +215,40 @@ def quick_workload(A, ctx, name, seed, steps=3):
             "candidate_evals_per_s": (cnt["evals"] - cnt["evals_skipped"]) / dt, "kernel_ms": kms}
 
 
+def pairwise_bench(A, ctx, shapes=((15, 4_000_000), (50, 2_000_000)), reps=5):
+    """SURVEY §8(f).1, `DMatrix::from` (src/pedigree.rs:210-261): pairwise divergence of n samples over L aligned
+    sites, codes RESIDENT in HBM (one byte per sample and site).  One pass over the codes is the algorithmic traffic:
+    n*L bytes / kernel time against the HBM peak; the pair arithmetic (n(n-1)/2 pairs x L sites) is reported as
+    site-pairs/s next to it."""
+    import torch
+
+    out = []
+    for n, L in shapes:
+        g = torch.Generator(device="cuda")
+        g.manual_seed(1234 + n)
+        codes = torch.randint(0, 3, (n, L), dtype=torch.uint8, device="cuda", generator=g)
+        codes |= (torch.rand((n, L), device="cuda", generator=g) < 0.05).to(torch.uint8) * 0x80  # 5 % filtered sites
+        npairs = n * (n - 1) // 2
+        diff = torch.zeros(npairs, dtype=torch.int64, device="cuda")
+        both = torch.zeros(npairs, dtype=torch.int64, device="cuda")
+        dval = torch.zeros(npairs, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.pairwise_divergence_dev(codes.data_ptr(), n, L, diff.data_ptr(), both.data_ptr(), dval.data_ptr())
+        ms = [ctx.pairwise_divergence_dev(codes.data_ptr(), n, L, diff.data_ptr(), both.data_ptr(), dval.data_ptr())
+              for _ in range(reps)]
+        best, avg = min(ms), sum(ms) / len(ms)
+        # property check at full size: every pair compares the sites valid in both samples, 0 <= diff <= 2 * both
+        ok = bool(((diff >= 0) & (diff <= 2 * both) & (both > 0) & (both <= L)).all().item())
+        gbs = n * L / (avg * 1e-3) / 1e9
+        out.append({"samples": n, "sites": L, "pairs": npairs, "kernel_ms_avg": avg, "kernel_ms_min": best,
+                    "code_bytes": n * L, "achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+                    "site_pairs_per_s": npairs * L / (avg * 1e-3), "sane": ok})
+        del codes
+    return {"kernel": "abn_pairwise_bits_kernel (+ reduce, finish)", "bound": "hbm", "unit": "GB/s",
+            "what": "n*L code bytes (one pass) / HIP-event time of the call's kernels, inputs resident in HBM",
+            "shapes": out}
+
+
 def stream_probe(A, ctx, seed, steps=2, every=5, B=8192, tag="C5 shard"):
     """Short run of the HBM-facing configuration (a C5 shard, stream mode: the bootstrap observations of a fit
     are re-read on every evaluation) so that the bench line also carries the roofline of the kernel variant the
@@ -310,7 +344,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "g351", "c5s", "mp"])
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "g351", "c5s", "mp", "pw"])
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--execute-stuck-fits", action="store_true",
@@ -357,6 +391,21 @@ def main():
 
     A.load_library(build_if_missing=True)
     seed = 20260101
+    if args.workload == "pw":  # the pedigree-construction scan, its own JSON line
+        ctx = A.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        r = pairwise_bench(A, ctx, reps=max(3, args.steps))
+        big = r["shapes"][-1]
+        print(json.dumps({"metric": "pairwise divergence (DMatrix::from) code bytes/s", "value": big["achieved_GBps"],
+                          "unit": "GB/s", "n_gpus": 1, "steps": max(3, args.steps), "warmup": 1,
+                          "ms_per_step": big["kernel_ms_avg"], "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                          "config": {"workload": f"pairwise divergence, {big['samples']} samples x {big['sites']} sites, "
+                                                 "codes resident in HBM"},
+                          "roofline": {"bound": "hbm", "achieved": big["achieved_GBps"], "peak": HBM_PEAK_GBS,
+                                       "unit": "GB/s", "frac": big["frac"], "traffic": None},
+                          "pairwise": r}))
+        ctx.close()
+        return
     wl = make_workload(args.workload, rank, world)
     N, Wr, S, B = wl["gens"].shape[0], wl["wr"], wl["S"], wl["B"]
     stream = torch.cuda.current_stream().cuda_stream
@@ -496,6 +545,7 @@ def main():
                 result["pcie_inclusive"] = pcie_inclusive(A, ctx, wl, opts)
             result["extra_workloads"] = {n: quick_workload(A, ctx, n, seed) for n in ("c2", "c4", "g351")
                                          if n != args.workload}
+            result["pairwise"] = pairwise_bench(A, ctx)
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a one-GPU (rank 0) measurement
             bs = int(out["best_start"][0])
             if bs >= 0:

@@ -177,6 +177,11 @@ int abn_analyze(const double* raw, int64_t n_boot, double* out32);
  * 0/0).  Integer sums are exact, so the result does not depend on the device's summation order. */
 int abn_pairwise_divergence(abn_ctx* ctx, const uint8_t* codes, int32_t n_samples, int64_t n_sites,
                             uint64_t* diff, uint64_t* both, double* dvalue);
+/* The same on DEVICE-resident buffers (no PCIe in the call): dev_codes u8[n x n_sites]; dev_diff / dev_both
+ * u64[pairs], dev_dvalue f64[pairs], any of the three may be NULL.  kernel_ms (nullable): HIP-event time of the
+ * kernels of this call on the context's stream.  Returns after the work has completed. */
+int abn_pairwise_divergence_dev(abn_ctx* ctx, const void* dev_codes, int32_t n_samples, int64_t n_sites,
+                                void* dev_diff, void* dev_both, void* dev_dvalue, double* kernel_ms);
 
 /* ------------------------------------------------------------------ (4) batched, device-resident plan
  * One pedigree topology (t0,t1,t2 of N rows), W windows that differ in D / p0uu (the metaprofile loop,

@@ -1,0 +1,16 @@
+# GPU box: rocprofv3 kernel trace of the pairwise workload (bench.py --workload pw); prints the abn_* kernel lines
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+out=${1:-gpurun_out/pw_prof}
+rm -rf "$out" && mkdir -p "$out"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 bench.py --workload pw --steps 5 > "$out/bench.json" 2> "$out/kt.err"
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+tr = glob.glob(out + "/kt/*/*_kernel_trace.csv")[0]
+d = collections.defaultdict(list)
+for r in csv.DictReader(open(tr)):
+    if "abn" in r["Kernel_Name"]:
+        d[(r["Kernel_Name"][:60], r["Grid_Size_X"], r.get("LDS_Block_Size", ""))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for k, v in d.items():
+    print(k, "calls", len(v), "avg_us %.1f min_us %.1f" % (sum(v) / len(v), min(v)))
+PY

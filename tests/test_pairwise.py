@@ -71,3 +71,45 @@ def test_gpu_pairwise_degenerate(abn, gpu_ctx):
     assert d.size == 0
     d, b, v = gpu_ctx.pairwise_divergence(np.zeros((3, 0), dtype=np.uint8))    # no sites: 0/0
     assert np.all(b == 0) and np.all(np.isnan(v))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,L", [(15, 300_001), (50, 65_536), (9, 1_000_003), (95, 9_000)])
+def test_gpu_pairwise_device_resident_entry(abn, gpu_ctx, oracle, n, L):
+    """abn_pairwise_divergence_dev (codes and results stay in HBM) against the host entry and the oracle: persistent
+    counters over many tiles, byte-misaligned rows (odd L), word slices per pair block (n = 9, 15), more than
+    kPairThreads * kPairUnits pair blocks (n = 95: per-tile sums)."""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so.7")      # the HIP runtime the product library already holds (no second runtime: a
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]   # torch imported AFTER it would bring its own copy)
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(n + L)
+    status = rng.integers(0, 3, size=(n, L), dtype=np.uint8)
+    pmax = rng.uniform(0.9, 1.0, size=(n, L))
+    codes = _codes(status, pmax, 0.99)
+    npairs = n * (n - 1) // 2
+    bufs = [C.c_void_p() for _ in range(4)]
+    for ptr, size in zip(bufs, (codes.nbytes, 8 * npairs, 8 * npairs, 8 * npairs)):
+        assert hip.hipMalloc(C.byref(ptr), size) == 0
+    t, d, b, v = bufs
+    assert hip.hipMemcpy(t, codes.ctypes.data, codes.nbytes, 1) == 0
+    ms = gpu_ctx.pairwise_divergence_dev(t.value, n, L, d.value, b.value, v.value)
+    assert ms > 0
+    dd, db, dv = np.zeros(npairs, np.uint64), np.zeros(npairs, np.uint64), np.zeros(npairs)
+    for host, dev in ((dd, d), (db, b), (dv, v)):
+        assert hip.hipMemcpy(host.ctypes.data, dev, 8 * npairs, 2) == 0
+    for ptr in bufs:
+        hip.hipFree(ptr)
+    hd, hb, hv = gpu_ctx.pairwise_divergence(codes)
+    assert np.array_equal(dd, hd) and np.array_equal(db, hb) and np.array_equal(dv, hv, equal_nan=True)
+    Ls = min(L, 40_000)                                   # the oracle on a prefix it finishes quickly
+    wd, wb, wv = oracle.pairwise_divergence(status[:, :Ls], pmax[:, :Ls], 0.99)
+    gd, gb, gv = gpu_ctx.pairwise_divergence(np.ascontiguousarray(codes[:, :Ls]))
+    assert np.array_equal(gd, wd) and np.array_equal(gb, wb) and np.array_equal(gv, wv)
+    # linearity over the site axis: the whole equals the sum of two halves (size-independent property)
+    h = L // 2
+    d1, b1, _ = gpu_ctx.pairwise_divergence(np.ascontiguousarray(codes[:, :h]))
+    d2, b2, _ = gpu_ctx.pairwise_divergence(np.ascontiguousarray(codes[:, h:]))
+    assert np.array_equal(d1 + d2, hd) and np.array_equal(b1 + b2, hb)
