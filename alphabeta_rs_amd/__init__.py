@@ -49,7 +49,7 @@ EXPORTED_SYMBOLS = [
     "abn_plan_set_window_ids", "abn_plan_failed_windows",
     "abn_multi_create", "abn_multi_destroy", "abn_multi_last_error", "abn_multi_set_windows", "abn_multi_run",
     "abn_multi_sync", "abn_multi_shard", "abn_multi_raw_device_ptr", "abn_multi_download", "abn_multi_counters",
-    "abn_multi_rccl_available", "abn_reduction_tree", "abn_pairwise_divergence_dev",
+    "abn_multi_rccl_available", "abn_reduction_tree", "abn_pairwise_divergence_dev", "abn_multi_set_window_ids",
 ]
 
 
@@ -140,6 +140,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     L.abn_multi_last_error.argtypes = [vp]
     L.abn_multi_last_error.restype = C.c_char_p
     L.abn_multi_set_windows.argtypes = [vp, dp, dp, dp, dp]
+    L.abn_multi_set_window_ids.argtypes = [vp, u32p]
     L.abn_multi_run.argtypes = [vp]
     L.abn_multi_sync.argtypes = [vp]
     L.abn_multi_shard.argtypes = [vp, C.c_int32, i32p]
@@ -504,6 +505,10 @@ class MultiPlan:
             self.close()
         except Exception:
             pass
+
+    def set_window_ids(self, ids):
+        a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32).reshape(self.W)
+        self._check(self._L.abn_multi_set_window_ids(self._h, _u32p(a)))
 
     def set_windows(self, d_obs, p0uu, eqp=None, eqp_weight=None):
         d = _f64(d_obs, (self.W, self.N))

@@ -234,6 +234,16 @@ extern "C" int abn_multi_create(const int32_t* devices, int32_t n_devices, const
   return ABN_OK;
 }
 
+extern "C" int abn_multi_set_window_ids(abn_multi* m, const uint32_t* ids) {
+  if (!m) return ABN_ERR_INVALID_ARG;
+  for (int i = 0; i < m->n; ++i) {
+    if (!m->plan[(size_t)i]) continue;
+    const int rc = abn_plan_set_window_ids(m->plan[(size_t)i], ids ? ids + m->sh[(size_t)i].w0 : nullptr);
+    if (rc) return plan_fail(m, i, rc, "abn_plan_set_window_ids");
+  }
+  return ABN_OK;
+}
+
 extern "C" int abn_multi_set_windows(abn_multi* m, const double* d_obs, const double* p0uu, const double* eqp,
                                      const double* eqp_weight) {
   if (!m || !d_obs || !p0uu) return m ? fail(m, ABN_ERR_INVALID_ARG, "null window data") : ABN_ERR_INVALID_ARG;

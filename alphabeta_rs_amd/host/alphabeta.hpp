@@ -84,6 +84,56 @@ class Device {  // RAII abn_ctx
   abn_ctx* ctx_ = nullptr;
 };
 
+// HIP ordinals the batched entry points spread their work over (--devices a,b,c; default: the one default device).
+// More than one: abn_multi_* — a plan per device, windows (or, for a single pedigree, bootstraps) sharded in
+// contiguous blocks, the bootstrap tables gathered with RCCL over xGMI; byte-identical results for any device count.
+inline std::vector<int32_t>& device_list() {
+  static std::vector<int32_t> devs;
+  return devs;
+}
+inline std::vector<int32_t> parse_device_list(const std::string& arg) {
+  std::vector<int32_t> out;
+  std::stringstream ss(arg);
+  std::string tok;
+  while (std::getline(ss, tok, ',')) {
+    if (tok.empty()) continue;
+    char* end = nullptr;
+    const long v = std::strtol(tok.c_str(), &end, 10);
+    if (*end != '\0' || v < 0) throw Error(ABN_ERR_INVALID_ARG, "--devices expects a comma-separated list of HIP ordinals");
+    out.push_back((int32_t)v);
+  }
+  if (out.empty()) throw Error(ABN_ERR_INVALID_ARG, "--devices: empty list");
+  return out;
+}
+
+// RAII abn_multi
+class MultiDevice {
+ public:
+  MultiDevice(const std::vector<int32_t>& devs, const abn_options& opts, const double* gens, size_t n_rows, size_t n_windows,
+              size_t n_starts, size_t n_boot) {
+    const int rc = abn_multi_create(devs.data(), (int32_t)devs.size(), &opts, gens, (int32_t)n_rows, (int32_t)n_windows,
+                                    (int32_t)n_starts, (int32_t)n_boot, &m_);
+    if (rc) {
+      const std::string why = m_ ? abn_multi_last_error(m_) : "";
+      if (m_) abn_multi_destroy(m_);
+      m_ = nullptr;
+      throw Error(rc, std::string("abn_multi_create: ") + abn_status_string(rc) + " — " + why);
+    }
+  }
+  ~MultiDevice() {
+    if (m_) abn_multi_destroy(m_);
+  }
+  MultiDevice(const MultiDevice&) = delete;
+  MultiDevice& operator=(const MultiDevice&) = delete;
+  abn_multi* get() const { return m_; }
+  void check(int rc, const char* what) const {
+    if (rc) throw Error(rc, std::string(what) + ": " + abn_status_string(rc) + " — " + abn_multi_last_error(m_));
+  }
+
+ private:
+  abn_multi* m_ = nullptr;
+};
+
 inline Device& default_device(int ordinal = -1) {
   static int chosen = 0;
   if (ordinal >= 0) chosen = ordinal;
@@ -344,8 +394,31 @@ struct RunResult {
   double obs_steady_state;
 };
 
+// src/alphabeta.rs:23-59 on several GPUs: one window, the bootstraps sharded over the devices (every device repeats the
+// cheap multi-start phase: same inputs, same bits), tables gathered with RCCL.  Same bits as the one-device path.
+inline RunResult run_on_pedigree_multi(Pedigree pedigree, double p0uu, size_t iterations, const std::vector<int32_t>& devs) {
+  Device& dev = default_device();
+  const size_t n = pedigree.nrows();
+  std::vector<double> gens(n * 3), d(n);
+  for (size_t i = 0; i < n; ++i) {
+    for (size_t c = 0; c < 3; ++c) gens[i * 3 + c] = pedigree.at(i, c);
+    d[i] = pedigree.at(i, 3);
+  }
+  MultiDevice md(devs, dev.options, gens.data(), n, 1, iterations, iterations);
+  md.check(abn_multi_set_windows(md.get(), d.data(), &p0uu, nullptr, nullptr), "abn_multi_set_windows");  // eqp = p0uu, weight 1
+  md.check(abn_multi_run(md.get()), "abn_multi_run");
+  double m[4];
+  RawAnalysis raw;
+  raw.n_boot = iterations;
+  raw.rows.resize(iterations * 7);
+  md.check(abn_multi_download(md.get(), m, nullptr, nullptr, raw.rows.data(), nullptr, nullptr, nullptr), "abn_multi_download");
+  Analysis a = raw.analyze();
+  return RunResult{Model::from_ptr(m), a, std::move(raw), std::move(pedigree), 1.0 - p0uu};
+}
+
 // src/alphabeta.rs:23-59 with an already built pedigree
 inline RunResult run_on_pedigree(Pedigree pedigree, double p0uu, size_t iterations, const std::string& output) {
+  if (device_list().size() > 1) return run_on_pedigree_multi(std::move(pedigree), p0uu, iterations, device_list());
   auto [model, pred_div, residuals] = ab_neutral::run(pedigree, p0uu, p0uu, 1.0, iterations);
   auto [analysis, raw] = boot_model::run(pedigree, model, std::move(pred_div), std::move(residuals), p0uu, p0uu, 1.0,
                                          iterations, nullptr, output);

@@ -23,6 +23,7 @@ static void usage() {
       "  -o, --output <OUTPUT>          Relative or absolute path to an output directory, must exist, EXISTING FILES WILL BE OVERWRITTEN [default: .]\n"
       "      --seed <SEED>              Philox seed of start simplices, jitter and bootstrap indices [default: 20260101]\n"
       "      --device <N>               HIP device ordinal [default: 0]\n"
+      "      --devices <A,B,..>         several HIP devices: the bootstraps are sharded over them, tables gathered with RCCL\n"
       "      --lanes <G>                lanes of a wavefront per Nelder-Mead chain: 0 (auto), 8, 16, 32, 64\n"
       "      --pedigree <FILE>          use this pedigree file (src/pedigree.rs:62-79 format) instead of building one\n"
       "      --p0uu <X>                 proportion of unmethylated sites at G0 (required with --pedigree)\n"
@@ -37,6 +38,7 @@ int main(int argc, char** argv) {
   double p0uu_given = -1.0;
   uint64_t seed = 20260101ull;
   int device = 0, lanes = 0;
+  std::string devices_arg;
   auto need = [&](int& i) -> const char* {
     if (i + 1 >= argc) {
       std::fprintf(stderr, "error: a value is required for '%s' but none was supplied\n", argv[i]);
@@ -60,6 +62,7 @@ int main(int argc, char** argv) {
     else if (a == "-o" || a == "--output") args.output = val();
     else if (a == "--seed") seed = std::strtoull(val().c_str(), nullptr, 10);
     else if (a == "--device") device = std::atoi(val().c_str());
+    else if (a == "--devices") devices_arg = val();
     else if (a == "--lanes") lanes = std::atoi(val().c_str());
     else if (a == "--pedigree") ped_file = val();
     else if (a == "--p0uu") p0uu_given = std::strtod(val().c_str(), nullptr);
@@ -92,7 +95,12 @@ int main(int argc, char** argv) {
     return 2;
   }
   try {
+    if (!devices_arg.empty()) {
+      device_list() = parse_device_list(devices_arg);
+      device = device_list()[0];
+    }
     Device& dev = default_device(device);
+    if (device_list().empty()) device_list().push_back(device);
     dev.options.seed = seed;
     dev.options.lanes_per_chain = lanes;
     RunResult r;

@@ -111,23 +111,25 @@ inline Output alphabeta_multiple(const WindowArgs& args, uint32_t max_gene_lengt
       for (size_t i = 0; i < N; ++i) D[w * N + i] = wins[members[w]].ped.at(i, 3);
       p0uu[w] = wins[members[w]].p0uu;
     }
-    abn_plan* plan = nullptr;
-    dev.check(abn_plan_create(dev.get(), &dev.options, gens.data(), (int32_t)N, (int32_t)W, (int32_t)S, (int32_t)B,
-                              (uint32_t)wins[members[0]].index, 0, &plan),
-              "abn_plan_create");
     // every window draws from the Philox streams of ITS position in the (region, window) enumeration, whatever
     // windows failed before it and whichever topology group it landed in
     std::vector<uint32_t> ids(W);
     for (size_t w = 0; w < W; ++w) ids[w] = (uint32_t)wins[members[w]].index;
     std::vector<double> mod(W * 4), raw(W * B * 7);
     std::vector<int32_t> best(W);
-    int rc = abn_plan_set_window_ids(plan, ids.data());
-    if (!rc) rc = abn_plan_set_windows(plan, D.data(), p0uu.data(), nullptr, nullptr);
-    if (!rc) rc = abn_plan_run(plan);
-    if (!rc) rc = abn_plan_download(plan, mod.data(), nullptr, nullptr, raw.data(), nullptr, nullptr, best.data());
-    abn_plan_destroy(plan);
-    if (rc == ABN_ERR_NO_FINITE_FIT) rc = ABN_OK;  // per window below: best[w] < 0 is printed and skipped (:64-65)
-    dev.check(rc, "metaprofile plan");
+    // one plan per device (abn_multi_*: --devices; one device = one plan), windows in contiguous blocks, the bootstrap
+    // tables gathered with RCCL: the loop of src/cli/metaprofile.rs:50-72 in three launches per device
+    std::vector<int32_t> devs = device_list();
+    if (devs.empty()) devs.push_back(0);
+    {
+      MultiDevice md(devs, dev.options, gens.data(), N, W, S, B);
+      md.check(abn_multi_set_window_ids(md.get(), ids.data()), "abn_multi_set_window_ids");
+      md.check(abn_multi_set_windows(md.get(), D.data(), p0uu.data(), nullptr, nullptr), "abn_multi_set_windows");
+      md.check(abn_multi_run(md.get()), "abn_multi_run");
+      int rc = abn_multi_download(md.get(), mod.data(), nullptr, nullptr, raw.data(), nullptr, nullptr, best.data());
+      if (rc == ABN_ERR_NO_FINITE_FIT) rc = ABN_OK;  // per window below: best[w] < 0 is printed and skipped (:64-65)
+      md.check(rc, "metaprofile plan");
+    }
     for (size_t w = 0; w < W; ++w) {
       const size_t i = members[w];
       if (best[w] < 0) {

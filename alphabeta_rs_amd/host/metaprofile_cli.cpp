@@ -16,6 +16,7 @@ int main(int argc, char** argv) {
   std::string dist_file;
   uint64_t seed = 20260101ull;
   int device = 0;
+  std::string devices_arg;
   for (int i = 1; i < argc; ++i) {
     const std::string f = argv[i];
     auto val = [&]() -> std::string {
@@ -36,9 +37,11 @@ int main(int argc, char** argv) {
     else if (f == "--distribution") dist_file = val();
     else if (f == "--seed") seed = std::strtoull(val().c_str(), nullptr, 10);
     else if (f == "--device") device = std::atoi(val().c_str());
+    else if (f == "--devices") devices_arg = val();
     else if (f == "-h" || f == "--help") {
       std::puts("Usage: metaprofile_alphabeta -o <output-dir> [--name N] [-s step] [-w size] [-c cutoff] [-a]\n"
-                "       [--iterations 100] [--max-gene-length L] [--distribution FILE] [--seed S] [--device D]");
+                "       [--iterations 100] [--max-gene-length L] [--distribution FILE] [--seed S] [--device D]\n"
+                "       [--devices A,B,..]   windows sharded over several HIP devices, tables gathered with RCCL");
       return 0;
     } else {
       std::fprintf(stderr, "error: unexpected argument '%s' found\n", argv[i]);
@@ -51,7 +54,12 @@ int main(int argc, char** argv) {
   }
   std::printf("Starting run %s\n", a.name.c_str());
   try {
+    if (!devices_arg.empty()) {
+      device_list() = parse_device_list(devices_arg);
+      device = device_list()[0];
+    }
     Device& dev = default_device(device);
+    if (device_list().empty()) device_list().push_back(device);
     dev.options.seed = seed;
     std::vector<int> distribution;
     if (!dist_file.empty()) {

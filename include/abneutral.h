@@ -246,6 +246,8 @@ int abn_multi_create(const int32_t* devices, int32_t n_devices, const abn_option
                      int32_t n_boot, abn_multi** out);
 int abn_multi_destroy(abn_multi* m);
 const char* abn_multi_last_error(const abn_multi* m);
+/* ids[W] for ALL windows, before abn_multi_set_windows (as abn_plan_set_window_ids); NULL restores the default */
+int abn_multi_set_window_ids(abn_multi* m, const uint32_t* ids);
 /* D[W x N], p0uu[W], optional eqp[W], eqp_weight[W] for ALL windows (as abn_plan_set_windows) */
 int abn_multi_set_windows(abn_multi* m, const double* d_obs, const double* p0uu, const double* eqp,
                           const double* eqp_weight);

@@ -353,6 +353,19 @@ def test_alphabeta_cli_end_to_end(abn, gpu_ctx, golden, oracle, tmp_path):
     k, model, pred, resid, _, _ = _oracle_ab_neutral(oracle, abn, ped, p0, p0, 1.0, iters, seed, 8)
     wraw, _ = oracle.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, iters, lanes=8)
     assert np.array_equal(raw, wraw)
+    # --devices 0 goes through abn_multi_* (one device: no gather) and must write the same files
+    multi = tmp_path / "multi"
+    multi.mkdir()
+    r2 = subprocess.run([cli, "-i", str(iters), "-n", "./data/nodelist.txt", "-e", "./data/edgelist.txt", "-o", str(multi),
+                         "--seed", str(seed), "--devices", "0"], capture_output=True, text=True, cwd=str(gold))
+    assert r2.returncode == 0, r2.stdout + r2.stderr
+    assert np.array_equal(np.load(multi / "raw.npy"), raw)
+    assert (multi / "analysis.txt").read_text() == (tmp_path / "analysis.txt").read_text()
+    # the reference's bootstrap.png (src/boot_model.rs:105-109) from the file the CLI wrote
+    import sys
+    pr = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "scripts" / "plot_bootstrap.py"),
+                         str(tmp_path / "raw.npy")], capture_output=True, text=True)
+    assert pr.returncode == 0 and (tmp_path / "bootstrap.png").stat().st_size > 5000, pr.stderr
     an = dict(ln.split("\t") for ln in (tmp_path / "analysis.txt").read_text().splitlines())
     want = oracle.analyze(wraw)
     assert float(an["Alpha"]) == want[0, 0] and float(an["SDBeta"]) == want[1, 1]
@@ -512,27 +525,35 @@ def test_full_size_properties_c2_and_c4(abn, gpu_ctx, golden, oracle):
 
 
 def test_metaprofile_batch_driver(abn, gpu_ctx, golden, oracle, tmp_path):
-    """`metaprofile_alphabeta` (src/cli/metaprofile.rs:33-114): window directories as src/setup.rs writes them,
-    all windows fitted by one batched plan; results.txt and the (iterations, 7, windows) raw.npy against
-    per-window oracle runs.  A window without its nodelist is reported and skipped like :64-65."""
+    """`metaprofile_alphabeta` (src/cli/metaprofile.rs:33-114): window directories as src/setup.rs writes them, all
+    windows fitted by batched plans; results.txt and the (iterations, 7, windows) raw.npy against per-window oracle
+    runs.  A window without its nodelist IN THE MIDDLE of the enumeration is reported and skipped like :64-65, and one
+    window has a different pedigree topology (a plan of its own): every window must still draw from the Philox streams
+    of ITS position in the (region, window) enumeration.  The metaplot script runs on the real results.txt."""
     import shutil
     import subprocess
+    import sys
     from pathlib import Path
 
     from alphabeta_rs_amd import build as B
 
     B.build_host()
     gold = Path(__file__).resolve().parent / "golden"
-    dirs = [(r, w) for r in ("upstream", "gene", "downstream") for w in (0, 50)]
+    dirs = [(r, w) for r in ("upstream", "gene", "downstream") for w in (0, 50)]   # enumeration index 0..5
+    missing, other = ("gene", 0), ("upstream", 50)                                 # index 2 is skipped, index 1 differs
     for r, w in dirs:
         d = tmp_path / r / str(w)
         d.mkdir(parents=True)
-        if (r, w) != ("downstream", 50):
-            shutil.copy(gold / "data" / "nodelist.txt", d / "nodelist.txt")
-            shutil.copy(gold / "data" / "edgelist.txt", d / "edgelist.txt")
+        if (r, w) == missing:
+            continue
+        shutil.copy(gold / "data" / "edgelist.txt", d / "edgelist.txt")
+        nodes = (gold / "data" / "nodelist.txt").read_text()
+        if (r, w) == other:      # G4_8 not sampled: three samples, three pairs — another topology
+            nodes = nodes.replace("./data/methylome/G4_8.txt,4_8,4,Y", "./data/methylome/G4_8.txt,4_8,4,N")
+        (d / "nodelist.txt").write_text(nodes)
     iters, seed = 8, 123
     r = subprocess.run([str(B.META_CLI), "-o", str(tmp_path), "--name", "t", "-s", "50", "--iterations", str(iters),
-                        "--seed", str(seed)], capture_output=True, text=True, cwd=str(gold))
+                        "--seed", str(seed), "--devices", "0"], capture_output=True, text=True, cwd=str(gold))
     assert r.returncode == 0, r.stdout + r.stderr
     assert "Error: Error while building pedigree" in r.stdout           # the missing window
     raw = np.load(tmp_path / "raw.npy")
@@ -540,18 +561,25 @@ def test_metaprofile_batch_driver(abn, gpu_ctx, golden, oracle, tmp_path):
     lines = (tmp_path / "results.txt").read_text().splitlines()
     assert lines[0].startswith("run;window;cg_count;region;alpha;beta") and len(lines) == 1 + 5
     ped, p0 = golden["generated"], golden["p0uu_generated"]
-    for w in range(5):
-        s0 = abn.gen_start_simplices(seed, w, iters, ped[:, 3].max())
-        fits = oracle.fit_batch(ped, p0, p0, 1.0, s0, 10000, lanes=8)
-        k, model, pred, resid, _ = oracle.select_best(ped, p0, fits["best"])
-        wraw, _ = oracle.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, w, 0, iters, lanes=8)
-        assert np.array_equal(raw[:, :, w], wraw)
-        f = lines[1 + w].split(";")
-        assert f[0] == "t" and int(f[1]) == w and f[3] == ["upstream", "upstream", "gene", "gene", "downstream"][w]
+    ped3 = ped[[0, 1, 3]]                                                # pairs of (G0, G1_2, G4_2)
+    ok_index = [0, 1, 3, 4, 5]                                           # enumeration indices of the fitted windows
+    for k, widx in enumerate(ok_index):
+        pw = ped3 if widx == 1 else ped
+        tree = abn.reduction_tree(pw[:, :3])
+        s0 = abn.gen_start_simplices(seed, widx, iters, pw[:, 3].max())
+        fits = oracle.fit_batch(pw, p0, p0, 1.0, s0, 10000, lanes=tree)
+        _, model, pred, resid, _ = oracle.select_best(pw, p0, fits["best"])
+        wraw, _ = oracle.boot_model(pw, model, pred, resid, p0, p0, 1.0, seed, widx, 0, iters, lanes=tree)
+        assert np.array_equal(raw[:, :, k], wraw), (k, widx)
+        f = lines[1 + k].split(";")
+        assert f[0] == "t" and int(f[1]) == k and f[3] == ["upstream", "upstream", "gene", "downstream", "downstream"][k]
         assert float(f[4]) == model[0] and float(f[5]) == model[1]
         assert float(f[8]) == 1.0 - p0
         an = oracle.analyze(wraw)
         assert float(f[9]) == an[1, 0] and float(f[10]) == an[1, 1]
+    pr = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "scripts" / "plot_metaplot.py"),
+                         str(tmp_path / "results.txt")], capture_output=True, text=True)
+    assert pr.returncode == 0 and (tmp_path / "metaplot.png").stat().st_size > 5000, pr.stderr
 
 
 @pytest.mark.parametrize("no_skip", (1, 0))
