@@ -56,3 +56,12 @@ def test_product_does_not_import_oracle():
         if p.suffix in {".py", ".hip", ".hpp", ".h", ".cpp"}:
             t = p.read_text()
             assert "abn_oracle" not in t and "import oracle" not in t and "from oracle" not in t, p
+
+
+def test_integration_doc_lists_every_symbol():
+    """INTEGRATION.md's `extern "C"` block binds every entry point the header declares (and nothing else)."""
+    doc = (ROOT / "INTEGRATION.md").read_text()
+    block = doc[doc.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    bound = sorted(set(re.findall(r"pub fn (abn_[a-z0-9_]+)\(", block)))
+    assert bound == declared_symbols()
