@@ -161,6 +161,15 @@ static int pick_lanes(int n, int requested, int chain_stride) {
   while (g < 64 && (size_t)(kWave / g) * per_chain > kLdsTargetPerBlock) g *= 2;
   return g;
 }
+static bool fit_streams(int n, int chain_stride, int lanes);
+static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree);
+// Accumulators of the residual reduction tree.  Auto (lanes_per_chain == 0): twice the packed kernels' lanes per chain —
+// two accumulators per lane — so that a wavefront per chain reproduces it with one v_permlane swap per row
+// (abn_device.hpp: wave_tree_sum); pedigrees that are streamed, and explicit lane counts, sum one accumulator per lane.
+static int pick_tree(int n, int requested, int chain_stride, int lanes) {
+  if (requested != 0 || lanes >= kWave || fit_streams(n, chain_stride, lanes)) return lanes;
+  return 2 * lanes;
+}
 static int pick_rmax(int n, int lanes) {
   const int per = (n + lanes - 1) / lanes;
   if (per <= 1) return 1;
@@ -211,17 +220,20 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
   if (chains <= 0) return ABN_OK;
   const int ng = kWave / lanes;
   int rmax = pick_rmax(a.N, lanes);
-  // the reduction tree: packed kernels sum in their own lanes; a wavefront per chain reproduces the pedigree's tree
-  if (lanes != kWave || a.tree <= 0 || a.tree > kWave) a.tree = lanes;
-  if (lanes == kWave && a.tree < kWave && (rmax <= 0 || rmax > 8 || a.N > a.tree * kPackedRowsMax))
-    return set_err(c, ABN_ERR_INVALID_ARG, "internal: a wavefront per chain reproduces a smaller tree for resident pedigrees of at most 8 rows per accumulator only");
+  // the reduction tree: packed kernels run `lanes` or 2 x `lanes` accumulators; a wavefront per chain reproduces 32 or
+  // (pedigrees of up to 32 rows) 16 accumulators (wave_tree_sum)
+  if (a.tree <= 0 || a.tree > kWave) a.tree = lanes;
+  if (lanes != kWave && a.tree != lanes && a.tree != 2 * lanes)
+    return set_err(c, ABN_ERR_INVALID_ARG, "internal: a packed kernel runs its lane count or twice that many accumulators");
+  if (rmax <= 0 && a.tree != lanes) return set_err(c, ABN_ERR_INVALID_ARG, "internal: stream mode sums one accumulator per lane");
+  if (lanes == kWave && a.tree < kWave && !tree_on_wave_ok(a.N, a.chain_stride, a.tree))
+    return set_err(c, ABN_ERR_INVALID_ARG, "internal: this tree cannot run on one wavefront per chain");
   const int np = ((a.N + 1) & ~1) + ((a.K + 1) / 2);  // resident observations + this chain's triple list
   if (rmax > 0) {
     if ((size_t)ng * (size_t)(a.chain_stride + np) * sizeof(double) > kLdsResidentMax) rmax = 0;
     else a.chain_stride += np;
   }
-  if (rmax <= 0 && lanes == kWave && a.tree < kWave)
-    return set_err(c, ABN_ERR_INVALID_ARG, "internal: tree emulation needs a resident pedigree");
+  if (rmax <= 0 && a.tree != lanes) return set_err(c, ABN_ERR_INVALID_ARG, "internal: stream mode sums one accumulator per lane");
   // stream mode: rows shorter than one trip of the deep loop (kStreamBlocks x 4 rows x lanes) use the pair-loop variant
   if (rmax == 0 && a.N < 2 * kStreamBlocks * kStreamVec * lanes) rmax = -1;
   const size_t lds = (size_t)ng * (size_t)a.chain_stride * sizeof(double);
@@ -264,13 +276,14 @@ static long long spec_max_chains(int n_rows) {
   return pick_rmax(n_rows, kWave) <= 2 ? kPhaseASpecMax : kPhaseASpecMax * 2 / 3;
 }
 
-// a wavefront per chain can reproduce a tree of fewer accumulators (packed_tree_sum) for LDS-resident pedigrees of
-// up to eight rows per accumulator — every pedigree the auto rule gives such a tree
+// a wavefront per chain reproduces trees of 32 accumulators (resident pedigrees of up to eight rows per lane) and of
+// 16 accumulators (pedigrees of up to 32 rows: one row per lane in the lower half) — wave_tree_sum
 static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree) {
   if (tree >= kWave) return true;
   const int rmax = pick_rmax(n_rows, kWave);
   if (rmax <= 0 || rmax > 8) return false;
-  if (n_rows > tree * kPackedRowsMax) return false;
+  if (tree == 16 && n_rows > 32) return false;
+  if (tree != 16 && tree != 32) return false;
   const int np = ((n_rows + 1) & ~1) + n_rows / 2 + 1;
   return (size_t)(chain_stride + np) * sizeof(double) <= kLdsResidentMax;
 }
@@ -280,10 +293,6 @@ static bool spec_applicable(const FitArgs& a) {
   const int rmax = pick_rmax(a.N, kWave);
   if (rmax == 0 || rmax > 8) return false;  // 16 rows per lane: the plain resident kernel
   if (!tree_on_wave_ok(a.N, a.chain_stride, a.tree)) return false;
-  if (a.tree > 0 && a.tree < kWave) {  // the instantiated (rows per lane, rows per accumulator) pairs of launch_fit_spec
-    const int nq = packed_rows_bound(a.N, a.tree);
-    if (rmax == 8 || (rmax == 4 && nq < 4) || (rmax == 2 && nq < 2)) return false;
-  }
   const int np = (a.N + 1) & ~1;
   return (3 * (size_t)(a.chain_stride + np) + kSpecCommDoubles) * sizeof(double) <= kLdsResidentMax;
 }
@@ -296,31 +305,12 @@ static int launch_fit_spec(abn_ctx* c, FitArgs a, hipStream_t st) {
   const size_t lds = (3 * (size_t)a.chain_stride + kSpecCommDoubles) * sizeof(double);
   dim3 grid((unsigned)chains), block(4 * kWave);
   if (a.tree <= 0 || a.tree > kWave) a.tree = kWave;
-#define ABN_SPEC(R, Q) hipLaunchKernelGGL((abn_fit_spec_kernel<R, Q>), grid, block, lds, st, a)
-  if (a.tree < kWave) {  // the pedigree's tree has fewer accumulators than a wavefront has lanes: (rows per lane at 64
-    const int nq = packed_rows_bound(a.N, a.tree);  // lanes, rows per accumulator) — the combinations spec_applicable admits
-    const int key = rmax * 16 + nq;
-    switch (key) {
-      case 1 * 16 + 1: ABN_SPEC(1, 1); break;
-      case 1 * 16 + 2: ABN_SPEC(1, 2); break;
-      case 1 * 16 + 4: ABN_SPEC(1, 4); break;
-      case 1 * 16 + 8: ABN_SPEC(1, 8); break;
-      case 2 * 16 + 2: ABN_SPEC(2, 2); break;
-      case 2 * 16 + 4: ABN_SPEC(2, 4); break;
-      case 2 * 16 + 8: ABN_SPEC(2, 8); break;
-      case 4 * 16 + 4: ABN_SPEC(4, 4); break;
-      case 4 * 16 + 8: ABN_SPEC(4, 8); break;
-      default: return set_err(c, ABN_ERR_INVALID_ARG, "internal: no speculative kernel for this (rows, tree)");
-    }
-  } else {
-    switch (rmax) {
-      case 1: ABN_SPEC(1, 0); break;
-      case 2: ABN_SPEC(2, 0); break;
-      case 4: ABN_SPEC(4, 0); break;
-      default: ABN_SPEC(8, 0); break;
-    }
+  switch (rmax) {
+    case 1: hipLaunchKernelGGL(abn_fit_spec_kernel<1>, grid, block, lds, st, a); break;
+    case 2: hipLaunchKernelGGL(abn_fit_spec_kernel<2>, grid, block, lds, st, a); break;
+    case 4: hipLaunchKernelGGL(abn_fit_spec_kernel<4>, grid, block, lds, st, a); break;
+    default: hipLaunchKernelGGL(abn_fit_spec_kernel<8>, grid, block, lds, st, a); break;
   }
-#undef ABN_SPEC
   HIPCHK(c, hipGetLastError());
   return ABN_OK;
 }
@@ -376,7 +366,8 @@ extern "C" int abn_reduction_tree(const abn_options* opts, const double* generat
   const int rc = build_topology(generations, n_rows, 3, t);
   if (rc) return rc;
   const int lanes = pick_lanes(n_rows, o.lanes_per_chain, t.chain_stride);
-  *tree = fit_streams(n_rows, t.chain_stride, lanes) ? (lanes | ((kStreamVec - 1) << 8)) : lanes;
+  *tree = fit_streams(n_rows, t.chain_stride, lanes) ? (lanes | ((kStreamVec - 1) << 8))
+                                                     : pick_tree(n_rows, o.lanes_per_chain, t.chain_stride, lanes);
   return ABN_OK;
 }
 
@@ -586,6 +577,7 @@ extern "C" int abn_cost_batch(abn_ctx* c, const abn_options* opts, const double*
   a.cand = dcand.p;
   a.M = m;
   a.strict = o.strict_order ? 1 : 0;
+  a.tree = o.strict_order ? lanes : pick_tree(N, o.lanes_per_chain, t.chain_stride, lanes);
   a.cost = dcost.p;
   a.dt = ddt.p;
   a.puu = dpuu.p;
@@ -685,7 +677,7 @@ extern "C" int abn_fit_batch(abn_ctx* c, const abn_options* opts, const double* 
   a.info = dinfo.p;
   a.raw = nullptr;
   const int lanes = pick_lanes(N, o.lanes_per_chain, t.chain_stride);
-  a.tree = lanes;
+  a.tree = pick_tree(N, o.lanes_per_chain, t.chain_stride, lanes);
   rc = launch_fit(c, a, lanes, c->stream);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(best, dbest.p, dbest.bytes(), hipMemcpyDeviceToHost, c->stream));
@@ -704,7 +696,8 @@ struct abn_plan {
   DevTopology dtopo;
   int N = 0, W = 0, S = 0, B = 0;
   uint32_t window_offset = 0, boot_offset = 0;
-  int lanes = 16;    // the pedigree's reduction tree = lanes per chain of the packed (throughput) kernels
+  int lanes = 16;    // lanes per chain of the packed (throughput) kernels
+  int tree = 32;     // the pedigree's reduction tree (accumulators): lanes or 2 x lanes (pick_tree)
   int lanes_a = 64;  // phase A (few chains: latency-bound, one wavefront per chain is fastest)
   std::vector<uint32_t> wid_host;  // Philox window ids (abn_plan_set_window_ids); empty = window_offset + w
   DevBuf<uint32_t> wid;
@@ -766,16 +759,17 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
     return set_err(c, rc, abn_status_string(rc));
   }
   p->lanes = pick_lanes(n_rows, p->opt.lanes_per_chain, p->topo.chain_stride);
+  p->tree = pick_tree(n_rows, p->opt.lanes_per_chain, p->topo.chain_stride, p->lanes);
   p->lanes_a = p->lanes;
   // Phase A is latency-bound while its chains fit the machine about twice over (3 wavefronts x 1024 SIMDs): one
   // wavefront per chain then beats packing several chains into a wavefront, and below ~1000 chains the
   // four-wavefront speculative kernel beats both (scripts/phase_a_sweep.py, C3 topology: 1000 chains 2.6 / 3.2 /
   // 4.6 ms for speculative / 64 lanes / 16 lanes, 1500 chains 4.2 / 3.4 / 4.8; 4000 chains - / 4.6 / 5.9 ms;
   // 8000 chains - / 7.7 / 7.0 ms)
-  // The reduction tree stays the pedigree's (p->lanes) whichever kernel runs: results do not depend on the size of
+  // The reduction tree stays the pedigree's (p->tree) whichever kernel runs: results do not depend on the size of
   // the launch, hence not on how a job is sharded over GPUs.
   if (p->opt.lanes_per_chain == 0 && (long long)n_windows * n_starts <= kPhaseAWideMax &&
-      tree_on_wave_ok(n_rows, p->topo.chain_stride, p->lanes))
+      tree_on_wave_ok(n_rows, p->topo.chain_stride, p->tree))
     p->lanes_a = 64;
   if ((size_t)(kWave / p->lanes) * p->topo.chain_stride * sizeof(double) > kMaxDynLds ||
       ((size_t)p->topo.chain_stride + kSelChunk) * sizeof(double) > kMaxDynLds) {
@@ -920,7 +914,7 @@ static void fill_common(const abn_plan* p, FitArgs& a) {
   a.window_offset = p->window_offset;
   a.boot_offset = p->boot_offset;
   a.wid = p->wid.p;
-  a.tree = p->lanes;
+  a.tree = p->tree;
   a.W = p->W;
   a.shrink_variant = p->opt.shrink_on_failed_contraction ? 1 : 0;
   a.no_skip = p->opt.no_fixed_point_skip ? 1 : 0;

@@ -83,10 +83,12 @@ struct FitArgs {
   uint64_t seed;
   uint32_t window_offset, boot_offset;
   const uint32_t* wid;   // nullable [W]: the window's index in the Philox counters (default window_offset + w)
-  // Residual reduction tree (the oracle's `lanes`): a property of the PEDIGREE, not of the launch.  The packed
-  // kernels (G lanes per chain) need tree == G; the one-wavefront-per-chain kernels (abn_fit_kernel<64, RMAX > 0>,
-  // abn_fit_spec_kernel) reproduce the tree of 8, 16 or 32 accumulators bit for bit (packed_tree_sum), so that the
-  // kernel may be chosen by the size of the launch while the results stay those of the pedigree's tree.
+  // Residual reduction tree (the oracle's `lanes` = number of accumulators): a property of the PEDIGREE, not of the
+  // launch.  Accumulator v sums rows v, v + tree, v + 2 tree, ... in that order, then an xor-butterfly over the `tree`
+  // accumulators.  The packed kernels (G lanes per chain) run tree == G (one accumulator per lane: explicit
+  // lanes_per_chain) or tree == 2 G (two per lane: the auto rule) — the latter so that the one-wavefront-per-chain
+  // kernels (abn_fit_kernel<64, RMAX > 0>, abn_fit_spec_kernel) reproduce the same tree with one v_permlane swap per
+  // row (wave_tree_sum): the kernel is chosen by the size of the launch, the bits are the pedigree's.
   int tree;
   // chains: W windows x C chains
   int W, C;
@@ -494,72 +496,67 @@ __device__ __forceinline__ double group_sum_dpp(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// P4 + P5 of a chain that owns a whole wavefront, in the value tree of a pedigree whose packed kernels give a chain
-// `tree` < 64 lanes (FitArgs::tree).  The wavefront simply does what the packed kernel's group does, in 64/tree
-// identical copies: lane L works as accumulator l = L & (tree - 1) and sums rows l, l + tree, l + 2 tree, ...
-// (at most eight, the packed kernels' limit) in that order, then the xor-butterfly over `tree` lanes runs inside
-// every group of `tree` lanes at once — all 64 lanes end with the same bits as group_sum_dpp<tree> of the packed
-// kernel (lanes of different copies read the same LDS addresses: broadcasts, no bank conflicts).  Measured against
-// collecting a 64-lane layout's terms with v_permlane swaps (12 swaps + 8 dependent adds for 105 rows): the C3 phase
-// A went 1.14 -> 1.31 ms that way; the replicated form adds only the extra rows' arithmetic.
-// tq: this lane's row -> triple ids (element offsets into dt), two per register, for rows l + tree q.
+// P5 of a chain that owns a whole wavefront, in the value tree of `tree` accumulators (FitArgs::tree).  Lane L holds
+// t[q] = term of row L + 64 q (+0.0 for rows past the end).
+//   tree 64: every lane sums its own rows, then the xor-butterfly over 64 lanes.
+//   tree 32 (the packed kernels' 16 lanes x 2 accumulators): accumulator v sums rows v, v + 32, v + 64, ... = lanes
+//            v and v + 32 of q = 0, then of q = 1, ...: one v_permlane32_swap per row puts both into lane v; the
+//            butterfly runs over 32 lanes.  The swap replicates the halves, so all 64 lanes end with the same bits.
+//   tree 16 (8 lanes x 2 accumulators; the host admits it for N <= 32 only, where the rows live in lanes 0..31 of
+//            q = 0): one v_permlane16_swap, butterfly over 16 lanes, the result copied from the lower half.
+// acc starts at +0.0 and x + 0.0 == x bit for bit (no term is -0.0).  All 64 lanes must be active.
+// (Measured alternatives for a 16-accumulator tree on C3's 105 rows — collecting four segments per row with swaps, or
+// replicating the packed kernels' eight rows per lane — cost phase A 1.14 -> 1.31 / 1.28 ms; hence two accumulators per
+// lane in the packed kernels, which makes this one swap per row.)
 // ------------------------------------------------------------------------------------------------
-constexpr int kPackedRowsMax = 8;
-
-__device__ __forceinline__ void packed_row_ids(uint32_t (&tq)[kPackedRowsMax / 2], const uint16_t* tid, int N, int tree,
-                                               int lane) {
-  const int l = lane & (tree - 1);
-#pragma unroll
-  for (int q = 0; q < kPackedRowsMax / 2; ++q) tq[q] = 0u;
-#pragma unroll
-  for (int q = 0; q < kPackedRowsMax; ++q) {
-    const int i = l + tree * q;
-    if (i < N) tq[q / 2] |= (uint32_t)tid[i] << (16 * (q & 1));
-  }
+struct F64Pair {
+  double a, b;
+};
+// v_permlane16_swap with both operands = v: a = (r0, r0, r2, r2), b = (r1, r1, r3, r3) for v = rows (r0, r1, r2, r3)
+__device__ __forceinline__ F64Pair swap16_pair(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return {__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1])};
+}
+// v_permlane32_swap with both operands = v: a = (r0, r1, r0, r1), b = (r2, r3, r2, r3)
+__device__ __forceinline__ F64Pair swap32_pair(double v) {
+  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return {__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1])};
 }
 
-// NQ: compile-time bound of the rows per accumulator, ceil(N / tree) rounded up to a power of two (rows past the end
-// read row N-1 and add +0.0): straight-line code, all LDS reads first, then the arithmetic.
-template <int NQ>
-__device__ __forceinline__ double packed_tree_sum(const uint32_t (&tq)[kPackedRowsMax / 2], const double* dobs,
-                                                  const double* dtab, double ic, double pen, int N, int tree, int lane) {
-  static_assert(NQ >= 1 && NQ <= kPackedRowsMax, "rows per accumulator");
-  const int l = lane & (tree - 1);
-  double dv[NQ], tv[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int i = l + tree * q;
-    dv[q] = dobs[i < N ? i : N - 1];
-    tv[q] = dtab[(tq[q / 2] >> (16 * (q & 1))) & 0xffffu];
-  }
+template <int RMAX>
+__device__ __forceinline__ double wave_tree_sum(const double (&t)[RMAX], int tree) {
   double acc = 0.0;
+  if (tree >= 64) {
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const double r = dv[q] - ic - tv[q];
-    const double term = r * r + pen;
-    acc = acc + (((l + tree * q) < N) ? term : 0.0);  // x + 0.0 == x bit for bit (acc is never -0.0)
+    for (int q = 0; q < RMAX; ++q) acc = acc + t[q];
+    return group_sum_dpp<64>(acc);
   }
-  acc = acc + dpp_mov<kDppQuadXor1>(acc);
-  acc = acc + dpp_mov<kDppQuadXor2>(acc);
-  acc = acc + dpp_mov<kDppRowHalfMirror>(acc);
-  if (tree >= 16) acc = acc + dpp_mov<kDppRowMirror>(acc);
-  if (tree >= 32) acc = swap_sum<16>(acc);
-  return acc;
-}
-// host and device agree on the bound: 1, 2, 4 or 8
-__host__ __device__ inline int packed_rows_bound(int n_rows, int tree) {
-  const int nq = (n_rows + tree - 1) / tree;
-  return nq <= 1 ? 1 : (nq <= 2 ? 2 : (nq <= 4 ? 4 : 8));
-}
-__device__ __forceinline__ double packed_tree_sum_any(const uint32_t (&tq)[kPackedRowsMax / 2], const double* dobs,
-                                                      const double* dtab, double ic, double pen, int N, int tree,
-                                                      int lane) {
-  switch (packed_rows_bound(N, tree)) {  // uniform
-    case 1: return packed_tree_sum<1>(tq, dobs, dtab, ic, pen, N, tree, lane);
-    case 2: return packed_tree_sum<2>(tq, dobs, dtab, ic, pen, N, tree, lane);
-    case 4: return packed_tree_sum<4>(tq, dobs, dtab, ic, pen, N, tree, lane);
-    default: return packed_tree_sum<8>(tq, dobs, dtab, ic, pen, N, tree, lane);
+  if (tree == 32) {
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const F64Pair h = swap32_pair(t[q]);  // lanes 0..31: rows v + 64 q, then rows v + 32 + 64 q
+      acc = acc + h.a;
+      acc = acc + h.b;
+    }
+    return group_sum_dpp<32>(acc);          // lanes 32..63 mirror lanes 0..31
   }
+  const F64Pair s = swap16_pair(t[0]);      // tree 16: rows v and v + 16 of q = 0
+  acc = acc + s.a;
+  acc = acc + s.b;
+  acc = group_sum_dpp<16>(acc);
+  return swap32_pair(acc).a;                // the lower half's result in every lane
+}
+
+// P5 of the packed kernels: a0 (and a1 when the tree has two accumulators per lane: accumulators gl and gl + G)
+template <int G>
+__device__ __forceinline__ double packed_tree_finish(double a0, double a1, bool two) {
+  const double s0 = group_sum_dpp<G>(a0);
+  if (!two) return s0;
+  return s0 + group_sum_dpp<G>(a1);         // the butterfly's last step: accumulators v and v ^ G
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -619,29 +616,24 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
   }
   // ---- resident mode: observed divergences staged in LDS once per fit (bootstrap: gathered through the
   // index row); this lane's triples and row->triple ids (as LDS byte offsets into dt) in registers
-  // two 16-bit triple ids per register: rows gl + G q — or, for a wavefront per chain that reproduces a tree of fewer
-  // accumulators (FitArgs::tree < 64, uniform per launch), rows (gl & (tree - 1)) + tree q of packed_tree_sum
-  constexpr bool MAYPACK = !STREAM && G == kWave && RR <= 8;
-  constexpr int NTID = MAYPACK ? kPackedRowsMax / 2 : (RR + 1) / 2;
-  uint32_t tidp[NTID];
-  const bool packed = MAYPACK && a.tree < kWave;
+  uint32_t tidp[(RR + 1) / 2];  // two 16-bit triple ids per register
+  // the tree's accumulators: one per lane (tree == G), two per lane in the packed kernels (tree == 2 G: even / odd rows
+  // of a lane), or fewer than lanes when a wavefront serves one chain (wave_tree_sum)
+  const bool two_acc = !STREAM && G < kWave && a.tree == 2 * G;
   uint32_t* tri_s = reinterpret_cast<uint32_t*>(dobs + ((N + 1) & ~1));  // this chain's copy of the triple list
   if (!STREAM) {
     for (int t = gl; t < K; t += G) tri_s[t] = a.tri[t];
 #pragma unroll
-    for (int q = 0; q < NTID; ++q) tidp[q] = 0u;
+    for (int q = 0; q < (RR + 1) / 2; ++q) tidp[q] = 0u;
 #pragma unroll
     for (int q = 0; q < RR; ++q) {
       const int i = gl + G * q;
       if (i < N) {
-        if (!packed) tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
+        tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
         dobs[i] = (a.dmode == 1) ? a.pred[wN + i] + a.resid[wN + idx_row[i]]  // src/boot_model.rs:50-54
                                  : a.D[dN + i];
       }
     }
-  }
-  if constexpr (MAYPACK) {
-    if (packed) packed_row_ids(tidp, a.tid, N, a.tree, lane);
   }
   __syncthreads();
 
@@ -707,15 +699,11 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
     ABN_STAMP(2);
     double acc = 0.0;                                        // P4
     bool summed = false;
-    if constexpr (MAYPACK) {
-      if (packed) {                                          // the pedigree's tree has fewer accumulators than lanes
-        acc = packed_tree_sum_any(tidp, dobs, dtab, ic, pen, N, a.tree, lane);  // P4 + P5 as the packed kernels' groups
-        summed = true;
-      }
-    }
-    if (summed) {
-    } else if (!STREAM) {
+    if (!STREAM) {
       constexpr int RC = RR < 8 ? RR : 8;                    // eight rows per lane at a time
+      double acc1 = 0.0;                                     // the odd rows' accumulator (two_acc)
+      double wt_[(G == kWave && RR <= 8) ? RR : 1];          // terms for wave_tree_sum
+      const bool wave_tree = G == kWave && RR <= 8 && a.tree < kWave;
 #pragma unroll
       for (int q0 = 0; q0 < RR; q0 += RC) {
         double dv[RC], tv[RC];
@@ -725,12 +713,34 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
           dv[q] = dobs[i < N ? i : N - 1];
           tv[q] = dtab[(tidp[(q0 + q) / 2] >> (16 * ((q0 + q) & 1))) & 0xffffu];
         }
+        double x[RC];
 #pragma unroll
         for (int q = 0; q < RC; ++q) {
           const double r = dv[q] - ic - tv[q];
           const double term = r * r + pen;
-          acc = acc + (((gl + G * (q0 + q)) < N) ? term : 0.0);  // x + 0.0 == x bit for bit (acc is never -0.0)
+          x[q] = ((gl + G * (q0 + q)) < N) ? term : 0.0;     // x + 0.0 == x bit for bit (acc is never -0.0)
+          if constexpr (G == kWave && RR <= 8) wt_[q0 + q] = x[q];
         }
+        if (G < kWave && two_acc) {                          // uniform: odd rows of a lane feed accumulator gl + G
+#pragma unroll
+          for (int q = 0; q < RC; ++q) {
+            if ((q0 + q) & 1) acc1 = acc1 + x[q];
+            else acc = acc + x[q];
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < RC; ++q) acc = acc + x[q];
+        }
+      }
+      if constexpr (G == kWave && RR <= 8) {
+        if (wave_tree) {                                     // fewer accumulators than lanes: the tree's own order
+          acc = wave_tree_sum<RR>(wt_, a.tree);
+          summed = true;
+        }
+      }
+      if constexpr (G < kWave) {
+        acc = packed_tree_finish<G>(acc, acc1, two_acc);     // P5
+        summed = true;
       }
     } else {
       // stream mode.  Lane l owns row blocks of kStreamVec = 4 consecutive rows: rows 4(l + G q) .. +3 for
@@ -1016,7 +1026,7 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
       fo.iters = iter;
       fo.evals = evals;
       fo.status = fin_status;
-      fo.lanes = STREAM ? (G | ((kStreamVec - 1) << 8)) : (G == kWave ? a.tree : G);  // reduction-tree code (oracle: `lanes`)
+      fo.lanes = STREAM ? (G | ((kStreamVec - 1) << 8)) : a.tree;  // reduction-tree code (oracle: `lanes`)
       a.info[chain] = fo;
     }
     if (a.raw) {
@@ -1065,6 +1075,7 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
   uint32_t* tri_s = reinterpret_cast<uint32_t*>(dobs + ((N + 1) & ~1));  // this group's copy of the triple list
 
   // ---- per-group constants of the topology: triple list in LDS, this lane's row -> triple ids in registers
+  const bool two_acc = G < kWave && a.tree == 2 * G;  // two accumulators per lane (FitArgs::tree)
   uint32_t tidp[(RR + 1) / 2];
   for (int t = gl; t < K; t += G) tri_s[t] = a.tri[t];
 #pragma unroll
@@ -1162,11 +1173,11 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
       tr = trn;
     }
     __syncthreads();
-    double acc = 0.0;                                        // P4
+    double acc = 0.0, acc1 = 0.0;                            // P4: one or (tree == 2 G) two accumulators per lane
     constexpr int RC = RR < 8 ? RR : 8;
 #pragma unroll
     for (int q0 = 0; q0 < RR; q0 += RC) {
-      double dv[RC], tv[RC];
+      double dv[RC], tv[RC], x[RC];
 #pragma unroll
       for (int q = 0; q < RC; ++q) {
         const int i = gl + G * (q0 + q);
@@ -1177,10 +1188,21 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
       for (int q = 0; q < RC; ++q) {
         const double r = dv[q] - ic - tv[q];
         const double term = r * r + pen;
-        acc = acc + (((gl + G * (q0 + q)) < N) ? term : 0.0);
+        x[q] = ((gl + G * (q0 + q)) < N) ? term : 0.0;
+      }
+      if (G < kWave && two_acc) {
+#pragma unroll
+        for (int q = 0; q < RC; ++q) {
+          if ((q0 + q) & 1) acc1 = acc1 + x[q];
+          else acc = acc + x[q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < RC; ++q) acc = acc + x[q];
       }
     }
-    acc = group_sum_dpp<G>(acc);                             // P5
+    if constexpr (G < kWave) acc = packed_tree_finish<G>(acc, acc1, two_acc);  // P5
+    else acc = group_sum_dpp<G>(acc);
     __syncthreads();
     return acc;
   };
@@ -1311,7 +1333,7 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
           fo.iters = iter;
           fo.evals = evals;
           fo.status = fin_status;
-          fo.lanes = G;  // reduction-tree code (oracle: `lanes`)
+          fo.lanes = a.tree;  // reduction-tree code (oracle: `lanes`)
           a.info[chain] = fo;
           nxt = gridDim.x * NG + atomicAdd(a.queue, 1u);
         }
@@ -1369,12 +1391,8 @@ constexpr int kSpecPreDoubles = kSpecOutcomes * 3 * 12;             // [outcome]
 constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16 + 2 * kSpecPreDoubles + 16;  // cost exchange, two candidate
                                                  // tables, shrink points, two tables of prepared inputs, two control blocks
 
-// NQ > 0: the pedigree's tree has fewer than 64 accumulators (FitArgs::tree) and at most NQ rows per accumulator
-// (packed_tree_sum<NQ>) — a template parameter so that the two row layouts never compete for registers (the kernel
-// sits at its VGPR limit: three workgroups per CU) and P4 is straight-line code.  NQ = 0: 64 accumulators.
-template <int RMAX, int NQ>
+template <int RMAX>
 __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_kernel(const FitArgs a) {
-  constexpr bool PACKED = NQ > 0;
   constexpr int G = kWave;
   extern __shared__ __align__(16) double lds[];
   const int wv = threadIdx.x >> 6;      // 0: reflection, 1: expansion, 2: contraction, 3: keeper
@@ -1396,15 +1414,11 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
 
   const int wi = w * a.wstride;
   const size_t wN = (size_t)w * (size_t)N;
-  constexpr int NTID = PACKED ? kPackedRowsMax / 2 : (RMAX + 1) / 2;
-  uint32_t triv[RMAX], tidp[NTID];  // row -> triple ids of this lane's rows: gl + 64 q, or (PACKED) (gl & (tree-1)) + tree q
+  uint32_t triv[RMAX], tidp[(RMAX + 1) / 2];
 #pragma unroll
-  for (int q = 0; q < NTID; ++q) tidp[q] = 0u;
+  for (int q = 0; q < (RMAX + 1) / 2; ++q) tidp[q] = 0u;
 #pragma unroll
   for (int q = 0; q < RMAX; ++q) triv[q] = 0u;
-  if constexpr (PACKED) {
-    if (!keeper) packed_row_ids(tidp, a.tid, N, a.tree, gl);
-  }
   // keeper state: the simplex, this lane's dimension of the five vertices in rank order
   double vx[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   if (!keeper) {
@@ -1421,7 +1435,7 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
       const int i = gl + G * q;
       triv[q] = (i < K) ? a.tri[i] : 0u;
       if (i < N) {
-        if constexpr (!PACKED) tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
+        tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
         dobs[i] = (a.dmode == 1) ? a.pred[wN + i] + a.resid[wN + idx_row[i]]  // src/boot_model.rs:50-54
                                  : a.D[wN + i];
       }
@@ -1495,16 +1509,22 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
     wave_lds_fence();
     ABN_STAMP(2);
     double acc = 0.0;
-    if constexpr (PACKED) {  // the pedigree's tree has fewer accumulators than lanes (FitArgs::tree)
-      acc = packed_tree_sum<(NQ > 0 ? NQ : 1)>(tidp, dobs, dtab, ic, pen, N, a.tree, gl);
-    } else {
-      double dv[RMAX], tv[RMAX];
+    double dv[RMAX], tv[RMAX];
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const bool in = (gl + G * q) < N;
+      dv[q] = in ? dobs[gl + G * q] : 0.0;
+      tv[q] = in ? dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu] : 0.0;
+    }
+    if (a.tree < kWave) {  // the pedigree's tree has fewer accumulators than lanes (FitArgs::tree; RMAX <= 4 then)
+      double term[RMAX];
 #pragma unroll
       for (int q = 0; q < RMAX; ++q) {
-        const bool in = (gl + G * q) < N;
-        dv[q] = in ? dobs[gl + G * q] : 0.0;
-        tv[q] = in ? dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu] : 0.0;
+        const double r = dv[q] - ic - tv[q];
+        term[q] = ((gl + G * q) < N) ? (r * r + pen) : 0.0;
       }
+      acc = wave_tree_sum<RMAX>(term, a.tree);
+    } else {
 #pragma unroll
       for (int q = 0; q < RMAX; ++q) {
         if ((gl + G * q) < N) {
@@ -1996,6 +2016,7 @@ struct CostArgs {
   const double* cand;         // [M*4]
   long long M;
   int strict;
+  int tree;                   // accumulators of the residual tree: G or 2 G (FitArgs::tree)
   double* cost;               // [M]
   double* dt;                 // nullable [M*N]
   double* puu;                // nullable [M]
@@ -2048,13 +2069,18 @@ __global__ __launch_bounds__(kWave) void abn_cost_kernel(const CostArgs a) {
     }
     result = ssum;
   } else {
-    double acc = 0.0;
-    for (int i = gl; i < N; i += G) {
+    double acc = 0.0, acc1 = 0.0;
+    const bool two = G < kWave && a.tree == 2 * G;  // two accumulators per lane: rows gl + 2 G m and gl + G + 2 G m
+    int q = 0;
+    for (int i = gl; i < N; i += G, ++q) {
       const double d = a.dmode ? a.pred[i] + a.resid[idx_row[i]] : a.D[i];
       const double r = d - ic - dtab[a.tid[i]];
-      acc = acc + (r * r + pen);
+      const double x = r * r + pen;
+      if (two && (q & 1)) acc1 = acc1 + x;
+      else acc = acc + x;
     }
     result = group_sum<G>(acc);
+    if (two) result = result + group_sum<G>(acc1);
   }
   if (valid) {
     if (gl == 0) {

@@ -18,12 +18,12 @@ ROOT = Path(__file__).resolve().parent.parent
 def _pedigree(kind, golden):
     from alphabeta_rs_amd import synthetic
 
-    if kind == "c3":                      # N = 105: tree of 16 accumulators, two rows per lane on a wavefront
+    if kind == "c3":                      # N = 105: 16 lanes x 2 accumulators = tree of 32
         ped, p0 = synthetic.c3_pedigree()
         return ped, p0
-    if kind == "generated":               # N = 6: tree of 8
+    if kind == "generated":               # N = 6: 8 lanes x 2 accumulators = tree of 16
         return golden["generated"], golden["p0uu_generated"]
-    if kind == "mid":                     # N = 200: tree of 32, four rows per lane on a wavefront
+    if kind == "mid":                     # N = 200: 32 lanes x 2 accumulators = tree of 64
         rng = np.random.default_rng(5)
         t0 = np.where(rng.random(200) < 0.3, rng.integers(0, 4, 200), 0)
         t1 = t0 + rng.integers(0, 10 - t0 + 1)
@@ -33,7 +33,7 @@ def _pedigree(kind, golden):
     return golden["pedigree"], 0.75       # N = 351: tree of 64
 
 
-@pytest.mark.parametrize("kind,tree", (("c3", 16), ("generated", 8), ("mid", 32), ("golden351", 64)))
+@pytest.mark.parametrize("kind,tree", (("c3", 32), ("generated", 16), ("mid", 64), ("golden351", 64)))
 def test_results_do_not_depend_on_launch_size(abn, gpu_ctx, golden, oracle, kind, tree):
     """Auto options.  The same window fitted (1) alone — both phases on the four-wavefront speculative kernel —,
     (2) among 200 windows — phase A one wavefront per chain, phase B packed / persistent —, and (3) among 800

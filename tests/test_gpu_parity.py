@@ -348,10 +348,12 @@ def test_alphabeta_cli_end_to_end(abn, gpu_ctx, golden, oracle, tmp_path):
     raw = np.load(tmp_path / "raw.npy")
     assert raw.shape == (iters, 7)
     ped, p0 = golden["generated"], golden["p0uu_generated"]
-    # auto options: the 6-row pedigree's reduction tree has 8 accumulators whichever kernel runs (phase A: four
-    # wavefronts per chain reproducing that tree; phase B likewise)
-    k, model, pred, resid, _, _ = _oracle_ab_neutral(oracle, abn, ped, p0, p0, 1.0, iters, seed, 8)
-    wraw, _ = oracle.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, iters, lanes=8)
+    # auto options: the 6-row pedigree's reduction tree has 16 accumulators (8 lanes x 2) whichever kernel runs
+    # (here four wavefronts per chain reproducing that tree in both phases)
+    tree = abn.reduction_tree(ped[:, :3])
+    assert tree == 16
+    k, model, pred, resid, _, _ = _oracle_ab_neutral(oracle, abn, ped, p0, p0, 1.0, iters, seed, tree)
+    wraw, _ = oracle.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, iters, lanes=tree)
     assert np.array_equal(raw, wraw)
     # --devices 0 goes through abn_multi_* (one device: no gather) and must write the same files
     multi = tmp_path / "multi"
@@ -560,11 +562,12 @@ def test_metaprofile_batch_driver(abn, gpu_ctx, golden, oracle, tmp_path):
     assert raw.shape == (iters, 7, 5)
     lines = (tmp_path / "results.txt").read_text().splitlines()
     assert lines[0].startswith("run;window;cg_count;region;alpha;beta") and len(lines) == 1 + 5
-    ped, p0 = golden["generated"], golden["p0uu_generated"]
+    ped, p0_all = golden["generated"], golden["p0uu_generated"]
     ped3 = ped[[0, 1, 3]]                                                # pairs of (G0, G1_2, G4_2)
+    p0_three = 0.642544651312622   # p0uu of that window (Pedigree::build over the three samples' common sites; host mirror)
     ok_index = [0, 1, 3, 4, 5]                                           # enumeration indices of the fitted windows
     for k, widx in enumerate(ok_index):
-        pw = ped3 if widx == 1 else ped
+        pw, p0 = (ped3, p0_three) if widx == 1 else (ped, p0_all)
         tree = abn.reduction_tree(pw[:, :3])
         s0 = abn.gen_start_simplices(seed, widx, iters, pw[:, 3].max())
         fits = oracle.fit_batch(pw, p0, p0, 1.0, s0, 10000, lanes=tree)
@@ -684,7 +687,7 @@ def test_speculative_phase_a_all_branches(abn, gpu_ctx, golden, oracle, variant,
     out = plan.download(allow_failed_windows=True)
     plan.close()
     la = int(out["info_a"]["lanes"][0, 0])
-    assert la == 8 == abn.reduction_tree(ped[:, :3])    # the pedigree's tree, on four wavefronts per chain
+    assert la == 16 == abn.reduction_tree(ped[:, :3])   # the pedigree's tree (8 lanes x 2), on four wavefronts per chain
     assert out["best_start"][3] == -1 and np.all(out["info_a"]["status"][3] == 2)
     assert np.all(np.isnan(out["models"][3])) and np.all(np.isnan(out["pred"][3]))
     for w in range(W):
