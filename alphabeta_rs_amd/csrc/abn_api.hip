@@ -163,12 +163,13 @@ static int pick_lanes(int n, int requested, int chain_stride) {
 }
 static bool fit_streams(int n, int chain_stride, int lanes);
 static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree);
-// Accumulators of the residual reduction tree.  Auto (lanes_per_chain == 0): twice the packed kernels' lanes per chain —
-// two accumulators per lane — so that a wavefront per chain reproduces it with one v_permlane swap per row
-// (abn_device.hpp: wave_tree_sum); pedigrees that are streamed, and explicit lane counts, sum one accumulator per lane.
+// The residual reduction tree (FitArgs::tree; abn_fit_info.lanes).  Auto (lanes_per_chain == 0) and the pedigree
+// LDS-resident: the canonical 64-accumulator tree, which every kernel — packed, one wavefront per chain, four
+// wavefronts per chain — runs at its native cost.  Streamed pedigrees and explicit lane counts: one accumulator per
+// lane of the packed kernel.
 static int pick_tree(int n, int requested, int chain_stride, int lanes) {
-  if (requested != 0 || lanes >= kWave || fit_streams(n, chain_stride, lanes)) return lanes;
-  return 2 * lanes;
+  if (requested != 0 || fit_streams(n, chain_stride, lanes)) return lanes;
+  return kTreeCanon;
 }
 static int pick_rmax(int n, int lanes) {
   const int per = (n + lanes - 1) / lanes;
@@ -220,20 +221,15 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
   if (chains <= 0) return ABN_OK;
   const int ng = kWave / lanes;
   int rmax = pick_rmax(a.N, lanes);
-  // the reduction tree: packed kernels run `lanes` or 2 x `lanes` accumulators; a wavefront per chain reproduces 32 or
-  // (pedigrees of up to 32 rows) 16 accumulators (wave_tree_sum)
-  if (a.tree <= 0 || a.tree > kWave) a.tree = lanes;
-  if (lanes != kWave && a.tree != lanes && a.tree != 2 * lanes)
-    return set_err(c, ABN_ERR_INVALID_ARG, "internal: a packed kernel runs its lane count or twice that many accumulators");
-  if (rmax <= 0 && a.tree != lanes) return set_err(c, ABN_ERR_INVALID_ARG, "internal: stream mode sums one accumulator per lane");
-  if (lanes == kWave && a.tree < kWave && !tree_on_wave_ok(a.N, a.chain_stride, a.tree))
-    return set_err(c, ABN_ERR_INVALID_ARG, "internal: this tree cannot run on one wavefront per chain");
+  // the reduction tree: the canonical one (any resident kernel) or one accumulator per lane
+  if (a.tree != kTreeCanon) a.tree = lanes;
   const int np = ((a.N + 1) & ~1) + ((a.K + 1) / 2);  // resident observations + this chain's triple list
   if (rmax > 0) {
     if ((size_t)ng * (size_t)(a.chain_stride + np) * sizeof(double) > kLdsResidentMax) rmax = 0;
     else a.chain_stride += np;
   }
-  if (rmax <= 0 && a.tree != lanes) return set_err(c, ABN_ERR_INVALID_ARG, "internal: stream mode sums one accumulator per lane");
+  if (rmax <= 0 && a.tree == kTreeCanon)
+    return set_err(c, ABN_ERR_INVALID_ARG, "internal: the canonical tree needs an LDS-resident pedigree");
   // stream mode: rows shorter than one trip of the deep loop (kStreamBlocks x 4 rows x lanes) use the pair-loop variant
   if (rmax == 0 && a.N < 2 * kStreamBlocks * kStreamVec * lanes) rmax = -1;
   const size_t lds = (size_t)ng * (size_t)a.chain_stride * sizeof(double);
@@ -276,14 +272,11 @@ static long long spec_max_chains(int n_rows) {
   return pick_rmax(n_rows, kWave) <= 2 ? kPhaseASpecMax : kPhaseASpecMax * 2 / 3;
 }
 
-// a wavefront per chain reproduces trees of 32 accumulators (resident pedigrees of up to eight rows per lane) and of
-// 16 accumulators (pedigrees of up to 32 rows: one row per lane in the lower half) — wave_tree_sum
+// a wavefront per chain runs the canonical tree whenever the pedigree is LDS-resident at 64 lanes per chain
 static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree) {
-  if (tree >= kWave) return true;
+  if (tree != kTreeCanon) return tree == kWave;
   const int rmax = pick_rmax(n_rows, kWave);
-  if (rmax <= 0 || rmax > 8) return false;
-  if (tree == 16 && n_rows > 32) return false;
-  if (tree != 16 && tree != 32) return false;
+  if (rmax <= 0) return false;
   const int np = ((n_rows + 1) & ~1) + n_rows / 2 + 1;
   return (size_t)(chain_stride + np) * sizeof(double) <= kLdsResidentMax;
 }
@@ -304,7 +297,7 @@ static int launch_fit_spec(abn_ctx* c, FitArgs a, hipStream_t st) {
   a.chain_stride += (a.N + 1) & ~1;
   const size_t lds = (3 * (size_t)a.chain_stride + kSpecCommDoubles) * sizeof(double);
   dim3 grid((unsigned)chains), block(4 * kWave);
-  if (a.tree <= 0 || a.tree > kWave) a.tree = kWave;
+  a.tree = kTreeCanon;  // spec_applicable admitted it
   switch (rmax) {
     case 1: hipLaunchKernelGGL(abn_fit_spec_kernel<1>, grid, block, lds, st, a); break;
     case 2: hipLaunchKernelGGL(abn_fit_spec_kernel<2>, grid, block, lds, st, a); break;

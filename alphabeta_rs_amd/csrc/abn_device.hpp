@@ -83,12 +83,15 @@ struct FitArgs {
   uint64_t seed;
   uint32_t window_offset, boot_offset;
   const uint32_t* wid;   // nullable [W]: the window's index in the Philox counters (default window_offset + w)
-  // Residual reduction tree (the oracle's `lanes` = number of accumulators): a property of the PEDIGREE, not of the
-  // launch.  Accumulator v sums rows v, v + tree, v + 2 tree, ... in that order, then an xor-butterfly over the `tree`
-  // accumulators.  The packed kernels (G lanes per chain) run tree == G (one accumulator per lane: explicit
-  // lanes_per_chain) or tree == 2 G (two per lane: the auto rule) — the latter so that the one-wavefront-per-chain
-  // kernels (abn_fit_kernel<64, RMAX > 0>, abn_fit_spec_kernel) reproduce the same tree with one v_permlane swap per
-  // row (wave_tree_sum): the kernel is chosen by the size of the launch, the bits are the pedigree's.
+  // Residual reduction tree (the oracle's `lanes` code): a property of the PEDIGREE, not of the launch.
+  //   kTreeCanon (auto options, every LDS-resident pedigree): 64 accumulators — accumulator v sums rows v, v + 64, ...
+  //     in that order — combined from the high lane bits down: v^32, v^16, v^8, then v <-> 7-v inside 8, v <-> 3-v
+  //     inside 4, v^1.  EVERY kernel runs it at its native cost: a wavefront per chain holds one accumulator per lane
+  //     (two permlane swaps, four DPP steps); the packed kernels hold the 64/G accumulators v = gl + G j of a chain in
+  //     each lane, combine them in registers (that is the v^32, v^16 (, v^8) part) and finish with the same DPP steps.
+  //     So the kernel is chosen by the size of the launch and the bits are the pedigree's (tree64_finish).
+  //   G (explicit lanes_per_chain, packed kernels only) or G | 3 << 8 (streamed pedigrees): G accumulators, one per
+  //     lane, xor-butterfly 1, 2, 4, ... (group_sum_dpp).
   int tree;
   // chains: W windows x C chains
   int W, C;
@@ -496,67 +499,43 @@ __device__ __forceinline__ double group_sum_dpp(double v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// P5 of a chain that owns a whole wavefront, in the value tree of `tree` accumulators (FitArgs::tree).  Lane L holds
-// t[q] = term of row L + 64 q (+0.0 for rows past the end).
-//   tree 64: every lane sums its own rows, then the xor-butterfly over 64 lanes.
-//   tree 32 (the packed kernels' 16 lanes x 2 accumulators): accumulator v sums rows v, v + 32, v + 64, ... = lanes
-//            v and v + 32 of q = 0, then of q = 1, ...: one v_permlane32_swap per row puts both into lane v; the
-//            butterfly runs over 32 lanes.  The swap replicates the halves, so all 64 lanes end with the same bits.
-//   tree 16 (8 lanes x 2 accumulators; the host admits it for N <= 32 only, where the rows live in lanes 0..31 of
-//            q = 0): one v_permlane16_swap, butterfly over 16 lanes, the result copied from the lower half.
-// acc starts at +0.0 and x + 0.0 == x bit for bit (no term is -0.0).  All 64 lanes must be active.
-// (Measured alternatives for a 16-accumulator tree on C3's 105 rows — collecting four segments per row with swaps, or
-// replicating the packed kernels' eight rows per lane — cost phase A 1.14 -> 1.31 / 1.28 ms; hence two accumulators per
-// lane in the packed kernels, which makes this one swap per row.)
+// The canonical residual tree (FitArgs::tree == kTreeCanon): 64 accumulators, high lane bits first.
 // ------------------------------------------------------------------------------------------------
-struct F64Pair {
-  double a, b;
-};
-// v_permlane16_swap with both operands = v: a = (r0, r0, r2, r2), b = (r1, r1, r3, r3) for v = rows (r0, r1, r2, r3)
-__device__ __forceinline__ F64Pair swap16_pair(double v) {
-  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-  const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  return {__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1])};
-}
-// v_permlane32_swap with both operands = v: a = (r0, r1, r0, r1), b = (r2, r3, r2, r3)
-__device__ __forceinline__ F64Pair swap32_pair(double v) {
-  const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-  const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  return {__hiloint2double((int)h[0], (int)l[0]), __hiloint2double((int)h[1], (int)l[1])};
-}
+constexpr int kTreeCanon = 0x10040;      // the oracle's `lanes` code: 64 accumulators | mirror-descending steps
+constexpr int kDppRowRor8 = 0x128;       // lane i <- lane i ^ 8 inside each 16 lanes
+constexpr int kDppQuadRev = 0x1B;        // quad_perm:[3,2,1,0]: lane i <-> 3 - i inside each quad
 
-template <int RMAX>
-__device__ __forceinline__ double wave_tree_sum(const double (&t)[RMAX], int tree) {
-  double acc = 0.0;
-  if (tree >= 64) {
-#pragma unroll
-    for (int q = 0; q < RMAX; ++q) acc = acc + t[q];
-    return group_sum_dpp<64>(acc);
-  }
-  if (tree == 32) {
-#pragma unroll
-    for (int q = 0; q < RMAX; ++q) {
-      const F64Pair h = swap32_pair(t[q]);  // lanes 0..31: rows v + 64 q, then rows v + 32 + 64 q
-      acc = acc + h.a;
-      acc = acc + h.b;
-    }
-    return group_sum_dpp<32>(acc);          // lanes 32..63 mirror lanes 0..31
-  }
-  const F64Pair s = swap16_pair(t[0]);      // tree 16: rows v and v + 16 of q = 0
-  acc = acc + s.a;
-  acc = acc + s.b;
-  acc = group_sum_dpp<16>(acc);
-  return swap32_pair(acc).a;                // the lower half's result in every lane
+// steps v <-> 7-v (inside 8), v <-> 3-v (inside 4), v ^ 1
+__device__ __forceinline__ double tree64_tail8(double v) {
+  v = v + dpp_mov<kDppRowHalfMirror>(v);
+  v = v + dpp_mov<kDppQuadRev>(v);
+  v = v + dpp_mov<kDppQuadXor1>(v);
+  return v;
 }
-
-// P5 of the packed kernels: a0 (and a1 when the tree has two accumulators per lane: accumulators gl and gl + G)
+// acc[j] = accumulator gl + G j of this lane's chain (G = 64: the lane's own).  Every lane of the group ends with the
+// chain's sum.
 template <int G>
-__device__ __forceinline__ double packed_tree_finish(double a0, double a1, bool two) {
-  const double s0 = group_sum_dpp<G>(a0);
-  if (!two) return s0;
-  return s0 + group_sum_dpp<G>(a1);         // the butterfly's last step: accumulators v and v ^ G
+__device__ __forceinline__ double tree64_finish(const double (&acc)[kWave / G]) {
+  double v;
+  if constexpr (G == 64) {
+    v = swap_sum<32>(acc[0]);                                  // v ^ 32
+    v = swap_sum<16>(v);                                       // v ^ 16
+    v = v + dpp_mov<kDppRowRor8>(v);                           // v ^ 8
+  } else if constexpr (G == 32) {
+    v = acc[0] + acc[1];                                       // v ^ 32: the lane's two accumulators
+    v = swap_sum<16>(v);
+    v = v + dpp_mov<kDppRowRor8>(v);
+  } else if constexpr (G == 16) {
+    const double b0 = acc[0] + acc[2], b1 = acc[1] + acc[3];   // v ^ 32
+    v = b0 + b1;                                               // v ^ 16
+    v = v + dpp_mov<kDppRowRor8>(v);
+  } else {
+    static_assert(G == 8, "lanes per chain");
+    const double b0 = acc[0] + acc[4], b1 = acc[1] + acc[5], b2 = acc[2] + acc[6], b3 = acc[3] + acc[7];
+    const double c0 = b0 + b2, c1 = b1 + b3;                   // v ^ 16
+    v = c0 + c1;                                               // v ^ 8
+  }
+  return tree64_tail8(v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -617,9 +596,7 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
   // ---- resident mode: observed divergences staged in LDS once per fit (bootstrap: gathered through the
   // index row); this lane's triples and row->triple ids (as LDS byte offsets into dt) in registers
   uint32_t tidp[(RR + 1) / 2];  // two 16-bit triple ids per register
-  // the tree's accumulators: one per lane (tree == G), two per lane in the packed kernels (tree == 2 G: even / odd rows
-  // of a lane), or fewer than lanes when a wavefront serves one chain (wave_tree_sum)
-  const bool two_acc = !STREAM && G < kWave && a.tree == 2 * G;
+  const bool canon = !STREAM && a.tree == kTreeCanon;  // the canonical 64-accumulator tree (FitArgs::tree), else G accumulators
   uint32_t* tri_s = reinterpret_cast<uint32_t*>(dobs + ((N + 1) & ~1));  // this chain's copy of the triple list
   if (!STREAM) {
     for (int t = gl; t < K; t += G) tri_s[t] = a.tri[t];
@@ -701,45 +678,35 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
     bool summed = false;
     if (!STREAM) {
       constexpr int RC = RR < 8 ? RR : 8;                    // eight rows per lane at a time
-      double acc1 = 0.0;                                     // the odd rows' accumulator (two_acc)
-      double wt_[(G == kWave && RR <= 8) ? RR : 1];          // terms for wave_tree_sum
-      const bool wave_tree = G == kWave && RR <= 8 && a.tree < kWave;
+      constexpr int NA = kWave / G;                          // canonical tree: accumulators gl + G j held by this lane
+      double av[NA];
+#pragma unroll
+      for (int j = 0; j < NA; ++j) av[j] = 0.0;
 #pragma unroll
       for (int q0 = 0; q0 < RR; q0 += RC) {
-        double dv[RC], tv[RC];
+        double dv[RC], tv[RC], x[RC];
 #pragma unroll
         for (int q = 0; q < RC; ++q) {                       // all LDS reads first, then the arithmetic;
           const int i = gl + G * (q0 + q);                   // rows past the end read row N-1 and add +0.0
           dv[q] = dobs[i < N ? i : N - 1];
           tv[q] = dtab[(tidp[(q0 + q) / 2] >> (16 * ((q0 + q) & 1))) & 0xffffu];
         }
-        double x[RC];
 #pragma unroll
         for (int q = 0; q < RC; ++q) {
           const double r = dv[q] - ic - tv[q];
           const double term = r * r + pen;
-          x[q] = ((gl + G * (q0 + q)) < N) ? term : 0.0;     // x + 0.0 == x bit for bit (acc is never -0.0)
-          if constexpr (G == kWave && RR <= 8) wt_[q0 + q] = x[q];
+          x[q] = ((gl + G * (q0 + q)) < N) ? term : 0.0;     // x + 0.0 == x bit for bit (no sum is -0.0)
         }
-        if (G < kWave && two_acc) {                          // uniform: odd rows of a lane feed accumulator gl + G
+        if (canon) {                                         // uniform: row gl + G q belongs to accumulator gl + G (q mod NA)
 #pragma unroll
-          for (int q = 0; q < RC; ++q) {
-            if ((q0 + q) & 1) acc1 = acc1 + x[q];
-            else acc = acc + x[q];
-          }
+          for (int q = 0; q < RC; ++q) av[(q0 + q) % NA] = av[(q0 + q) % NA] + x[q];
         } else {
 #pragma unroll
           for (int q = 0; q < RC; ++q) acc = acc + x[q];
         }
       }
-      if constexpr (G == kWave && RR <= 8) {
-        if (wave_tree) {                                     // fewer accumulators than lanes: the tree's own order
-          acc = wave_tree_sum<RR>(wt_, a.tree);
-          summed = true;
-        }
-      }
-      if constexpr (G < kWave) {
-        acc = packed_tree_finish<G>(acc, acc1, two_acc);     // P5
+      if (canon) {
+        acc = tree64_finish<G>(av);                          // P5, the pedigree's tree
         summed = true;
       }
     } else {
@@ -1075,7 +1042,7 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
   uint32_t* tri_s = reinterpret_cast<uint32_t*>(dobs + ((N + 1) & ~1));  // this group's copy of the triple list
 
   // ---- per-group constants of the topology: triple list in LDS, this lane's row -> triple ids in registers
-  const bool two_acc = G < kWave && a.tree == 2 * G;  // two accumulators per lane (FitArgs::tree)
+  const bool canon = a.tree == kTreeCanon;  // the canonical 64-accumulator tree (FitArgs::tree), else G accumulators
   uint32_t tidp[(RR + 1) / 2];
   for (int t = gl; t < K; t += G) tri_s[t] = a.tri[t];
 #pragma unroll
@@ -1173,8 +1140,12 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
       tr = trn;
     }
     __syncthreads();
-    double acc = 0.0, acc1 = 0.0;                            // P4: one or (tree == 2 G) two accumulators per lane
+    double acc = 0.0;                                        // P4
     constexpr int RC = RR < 8 ? RR : 8;
+    constexpr int NA = kWave / G;                            // canonical tree: accumulators gl + G j held by this lane
+    double av[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) av[j] = 0.0;
 #pragma unroll
     for (int q0 = 0; q0 < RR; q0 += RC) {
       double dv[RC], tv[RC], x[RC];
@@ -1190,19 +1161,15 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
         const double term = r * r + pen;
         x[q] = ((gl + G * (q0 + q)) < N) ? term : 0.0;
       }
-      if (G < kWave && two_acc) {
+      if (canon) {
 #pragma unroll
-        for (int q = 0; q < RC; ++q) {
-          if ((q0 + q) & 1) acc1 = acc1 + x[q];
-          else acc = acc + x[q];
-        }
+        for (int q = 0; q < RC; ++q) av[(q0 + q) % NA] = av[(q0 + q) % NA] + x[q];
       } else {
 #pragma unroll
         for (int q = 0; q < RC; ++q) acc = acc + x[q];
       }
     }
-    if constexpr (G < kWave) acc = packed_tree_finish<G>(acc, acc1, two_acc);  // P5
-    else acc = group_sum_dpp<G>(acc);
+    acc = canon ? tree64_finish<G>(av) : group_sum_dpp<G>(acc);  // P5
     __syncthreads();
     return acc;
   };
@@ -1516,23 +1483,16 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
       dv[q] = in ? dobs[gl + G * q] : 0.0;
       tv[q] = in ? dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu] : 0.0;
     }
-    if (a.tree < kWave) {  // the pedigree's tree has fewer accumulators than lanes (FitArgs::tree; RMAX <= 4 then)
-      double term[RMAX];
 #pragma unroll
-      for (int q = 0; q < RMAX; ++q) {
+    for (int q = 0; q < RMAX; ++q) {
+      if ((gl + G * q) < N) {
         const double r = dv[q] - ic - tv[q];
-        term[q] = ((gl + G * q) < N) ? (r * r + pen) : 0.0;
+        acc = acc + (r * r + pen);
       }
-      acc = wave_tree_sum<RMAX>(term, a.tree);
-    } else {
-#pragma unroll
-      for (int q = 0; q < RMAX; ++q) {
-        if ((gl + G * q) < N) {
-          const double r = dv[q] - ic - tv[q];
-          acc = acc + (r * r + pen);
-        }
-      }
-      acc = group_sum_dpp<G>(acc);
+    }
+    {  // P5: the canonical tree (this kernel runs under auto options only: FitArgs::tree == kTreeCanon)
+      const double one[1] = {acc};
+      acc = tree64_finish<G>(one);
     }
     wave_lds_fence();
     ABN_STAMP(3);
@@ -2016,7 +1976,7 @@ struct CostArgs {
   const double* cand;         // [M*4]
   long long M;
   int strict;
-  int tree;                   // accumulators of the residual tree: G or 2 G (FitArgs::tree)
+  int tree;                   // kTreeCanon or G accumulators (FitArgs::tree)
   double* cost;               // [M]
   double* dt;                 // nullable [M*N]
   double* puu;                // nullable [M]
@@ -2069,18 +2029,32 @@ __global__ __launch_bounds__(kWave) void abn_cost_kernel(const CostArgs a) {
     }
     result = ssum;
   } else {
-    double acc = 0.0, acc1 = 0.0;
-    const bool two = G < kWave && a.tree == 2 * G;  // two accumulators per lane: rows gl + 2 G m and gl + G + 2 G m
-    int q = 0;
-    for (int i = gl; i < N; i += G, ++q) {
-      const double d = a.dmode ? a.pred[i] + a.resid[idx_row[i]] : a.D[i];
-      const double r = d - ic - dtab[a.tid[i]];
-      const double x = r * r + pen;
-      if (two && (q & 1)) acc1 = acc1 + x;
-      else acc = acc + x;
+    if (a.tree == kTreeCanon) {  // the canonical 64-accumulator tree: this lane holds accumulators gl + G j
+      constexpr int NA = kWave / G;
+      double av[NA];
+#pragma unroll
+      for (int j = 0; j < NA; ++j) av[j] = 0.0;
+      for (int i0 = gl; i0 < N; i0 += kWave) {  // NA rows at a time keep av[] statically indexed
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          const int i = i0 + G * j;
+          if (i < N) {
+            const double d = a.dmode ? a.pred[i] + a.resid[idx_row[i]] : a.D[i];
+            const double r = d - ic - dtab[a.tid[i]];
+            av[j] = av[j] + (r * r + pen);
+          }
+        }
+      }
+      result = tree64_finish<G>(av);
+    } else {
+      double acc = 0.0;
+      for (int i = gl; i < N; i += G) {
+        const double d = a.dmode ? a.pred[i] + a.resid[idx_row[i]] : a.D[i];
+        const double r = d - ic - dtab[a.tid[i]];
+        acc = acc + (r * r + pen);
+      }
+      result = group_sum<G>(acc);
     }
-    result = group_sum<G>(acc);
-    if (two) result = result + group_sum<G>(acc1);
   }
   if (valid) {
     if (gl == 0) {

@@ -489,7 +489,8 @@ def main():
         T = int(wl["gens"].max())
         # ---- roofline of the dominant kernel (phase-B fit kernel), per launch on this rank
         fits_b, evals_b = Wr * B, int(out["info_b"]["evals"].sum()) - cnt["evals_skipped_boot"]
-        stream = (lanes >> 8) != 0        # row-block code set: the pedigree is streamed every evaluation
+        tree_code = lanes                 # abn_fit_info.lanes: the residual reduction tree of the pedigree
+        stream = ((lanes >> 8) & 0xff) != 0   # row-block code set: the pedigree is streamed every evaluation
         lanes &= 0xff
         if stream:
             # SURVEY.md §8(d) per-evaluation figure (4N + 40: the u32 index stream).  The default stream variant
@@ -507,7 +508,8 @@ def main():
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": f"abn_fit_kernel<G={lanes}> phase B", "kernel_ms": kms["fit_boot"],
+            "kernel": ("abn_fit_kernel<64, stream>" if stream else "abn_fit_kernel / abn_fit_refill_kernel (packed)") +
+                      " phase B", "kernel_ms": kms["fit_boot"],
             "algorithmic_bytes_per_launch": alg_bytes,
             "mode": "stream" if stream else "resident",
             **({"streamed_bytes_per_launch": streamed_bytes,
@@ -527,7 +529,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["label"], "rows": N, "windows_per_gpu": Wr, "starts": S, "bootstraps": B,
-                       "lanes_per_chain": lanes, "parallelism": f"{'bootstraps' if by_boot else 'windows'} sharded over {world} GPU(s), "
+                       "reduction_tree": hex(tree_code), "parallelism": f"{'bootstraps' if by_boot else 'windows'} sharded over {world} GPU(s), "
                                                                  "one RCCL all-gather of the bootstrap tables"},
             "candidate_evals_per_s": evals_per_s,
             "fits_per_step": tot_fits, "evals_per_step": tot_evals, "nm_iters_per_step": tot_iters,

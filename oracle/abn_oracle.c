@@ -205,7 +205,11 @@ double abo_cost(const double* ped, int n, const double* dobs, double p_uu, doubl
     } else {
       /* lanes code: low byte = lanes of the butterfly; (code >> 8) + 1 = consecutive rows per lane and block
        * (1: lane l takes rows l, l+lanes, ...; 4 (the stream kernel): rows 4(l + lanes q) .. +3) */
-      const int vec = (lanes >> 8) + 1;
+      /* bit 16 (with 64 lanes): the canonical tree of every LDS-resident pedigree — 64 accumulators, combined from
+       * the high lane bits down with the pairings the kernels' DPP / permlane steps realise:
+       * l^32, l^16, l^8, then l <-> 7-l inside 8, l <-> 3-l inside 4, l^1 (abn_device.hpp: tree64_finish) */
+      const int mirror = (lanes >> 16) & 1;
+      const int vec = ((lanes >> 8) & 0xff) + 1;
       lanes &= 0xff;
       double part[64];
       for (int l = 0; l < lanes; ++l) {
@@ -219,10 +223,29 @@ double abo_cost(const double* ped, int n, const double* dobs, double p_uu, doubl
           }
         part[l] = acc;
       }
-      for (int off = 1; off < lanes; off <<= 1) {
-        double nxt[64];
-        for (int l = 0; l < lanes; ++l) nxt[l] = part[l] + part[l ^ off];
-        memcpy(part, nxt, sizeof(double) * (size_t)lanes);
+      if (mirror && lanes == 64) {
+        for (int step = 0; step < 6; ++step) {
+          double nxt[64];
+          for (int l = 0; l < 64; ++l) {
+            int p;
+            switch (step) {
+              case 0: p = l ^ 32; break;
+              case 1: p = l ^ 16; break;
+              case 2: p = l ^ 8; break;
+              case 3: p = (l & ~7) | (7 - (l & 7)); break;
+              case 4: p = (l & ~3) | (3 - (l & 3)); break;
+              default: p = l ^ 1; break;
+            }
+            nxt[l] = part[l] + part[p];
+          }
+          memcpy(part, nxt, sizeof(double) * 64);
+        }
+      } else {
+        for (int off = 1; off < lanes; off <<= 1) {
+          double nxt[64];
+          for (int l = 0; l < lanes; ++l) nxt[l] = part[l] + part[l ^ off];
+          memcpy(part, nxt, sizeof(double) * (size_t)lanes);
+        }
       }
       result = part[0];
     }

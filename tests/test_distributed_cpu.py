@@ -89,16 +89,20 @@ def test_gloo_shard_and_gather_matches_unsharded(world, W, B, mode):
 
 def test_reduction_tree_is_a_function_of_the_pedigree_only(abn):
     """abn_reduction_tree takes generations and options — no fit counts: the tree cannot change with sharding.
-    Auto: twice the packed kernels' lanes per chain (two accumulators per lane) — C3's topology -> 32, the bundled
-    pedigree -> 16, the 351-row golden one -> 64; an explicit lanes_per_chain is the tree itself."""
+    Auto: the canonical 64-accumulator tree (0x10040) for every LDS-resident pedigree, whatever lane count its packed
+    kernels use; streamed pedigrees 64 | 3 << 8; an explicit lanes_per_chain is the (legacy) tree itself."""
     import oracle as O
     from alphabeta_rs_amd import synthetic
 
-    assert abn.reduction_tree(synthetic.c3_pedigree()[0][:, :3]) == 32
-    assert abn.reduction_tree(O.load_pedigree(ROOT / "tests" / "golden" / "pedigree_generated.txt")[:, :3]) == 16
-    assert abn.reduction_tree(O.load_pedigree(ROOT / "tests" / "golden" / "pedigree.txt")[:, :3]) == 64
+    canon = 0x10040
+    assert abn.reduction_tree(synthetic.c3_pedigree()[0][:, :3]) == canon
+    assert abn.reduction_tree(O.load_pedigree(ROOT / "tests" / "golden" / "pedigree_generated.txt")[:, :3]) == canon
+    assert abn.reduction_tree(O.load_pedigree(ROOT / "tests" / "golden" / "pedigree.txt")[:, :3]) == canon
     assert abn.reduction_tree(synthetic.c3_pedigree()[0][:, :3], abn.default_options(lanes_per_chain=32)) == 32
     assert abn.reduction_tree(synthetic.c3_pedigree()[0][:, :3], abn.default_options(lanes_per_chain=16)) == 16
+    big = np.zeros((3000, 3))
+    big[:, 1:] = 1.0
+    assert abn.reduction_tree(big) == (64 | (3 << 8))
 
 
 def test_bench_refuses_a_gpu_count_it_cannot_run():

@@ -18,12 +18,12 @@ ROOT = Path(__file__).resolve().parent.parent
 def _pedigree(kind, golden):
     from alphabeta_rs_amd import synthetic
 
-    if kind == "c3":                      # N = 105: 16 lanes x 2 accumulators = tree of 32
+    if kind == "c3":                      # N = 105: packed kernels with 16 lanes per chain (four accumulators each)
         ped, p0 = synthetic.c3_pedigree()
         return ped, p0
-    if kind == "generated":               # N = 6: 8 lanes x 2 accumulators = tree of 16
+    if kind == "generated":               # N = 6: packed kernels with 8 lanes per chain
         return golden["generated"], golden["p0uu_generated"]
-    if kind == "mid":                     # N = 200: 32 lanes x 2 accumulators = tree of 64
+    if kind == "mid":                     # N = 200: packed kernels with 32 lanes per chain
         rng = np.random.default_rng(5)
         t0 = np.where(rng.random(200) < 0.3, rng.integers(0, 4, 200), 0)
         t1 = t0 + rng.integers(0, 10 - t0 + 1)
@@ -33,7 +33,10 @@ def _pedigree(kind, golden):
     return golden["pedigree"], 0.75       # N = 351: tree of 64
 
 
-@pytest.mark.parametrize("kind,tree", (("c3", 32), ("generated", 16), ("mid", 64), ("golden351", 64)))
+CANON = 0x10040   # the canonical tree of every LDS-resident pedigree: 64 accumulators, high lane bits first
+
+
+@pytest.mark.parametrize("kind,tree", (("c3", CANON), ("generated", CANON), ("mid", CANON), ("golden351", CANON)))
 def test_results_do_not_depend_on_launch_size(abn, gpu_ctx, golden, oracle, kind, tree):
     """Auto options.  The same window fitted (1) alone — both phases on the four-wavefront speculative kernel —,
     (2) among 200 windows — phase A one wavefront per chain, phase B packed / persistent —, and (3) among 800

@@ -348,10 +348,10 @@ def test_alphabeta_cli_end_to_end(abn, gpu_ctx, golden, oracle, tmp_path):
     raw = np.load(tmp_path / "raw.npy")
     assert raw.shape == (iters, 7)
     ped, p0 = golden["generated"], golden["p0uu_generated"]
-    # auto options: the 6-row pedigree's reduction tree has 16 accumulators (8 lanes x 2) whichever kernel runs
-    # (here four wavefronts per chain reproducing that tree in both phases)
+    # auto options: the canonical 64-accumulator tree whichever kernel runs (here four wavefronts per chain in
+    # both phases)
     tree = abn.reduction_tree(ped[:, :3])
-    assert tree == 16
+    assert tree == 0x10040
     k, model, pred, resid, _, _ = _oracle_ab_neutral(oracle, abn, ped, p0, p0, 1.0, iters, seed, tree)
     wraw, _ = oracle.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, iters, lanes=tree)
     assert np.array_equal(raw, wraw)
@@ -687,7 +687,7 @@ def test_speculative_phase_a_all_branches(abn, gpu_ctx, golden, oracle, variant,
     out = plan.download(allow_failed_windows=True)
     plan.close()
     la = int(out["info_a"]["lanes"][0, 0])
-    assert la == 16 == abn.reduction_tree(ped[:, :3])   # the pedigree's tree (8 lanes x 2), on four wavefronts per chain
+    assert la == 0x10040 == abn.reduction_tree(ped[:, :3])   # the canonical tree, on four wavefronts per chain
     assert out["best_start"][3] == -1 and np.all(out["info_a"]["status"][3] == 2)
     assert np.all(np.isnan(out["models"][3])) and np.all(np.isnan(out["pred"][3]))
     for w in range(W):
@@ -725,8 +725,10 @@ def test_persistent_refill_kernel_is_schedule_independent(abn, gpu_ctx, golden, 
         plan.run()
         outs.append(plan.download())
         plan.close()
-    lanes = int(outs[0]["info_b"]["lanes"][0, 0])
-    assert W * B // (64 // lanes) > 3072                  # the persistent launch was taken
+    lanes = int(outs[0]["info_b"]["lanes"][0, 0])          # the canonical tree code, whatever the packed lane count
+    assert lanes == abn.reduction_tree(ped[:, :3]) == 0x10040
+    packed = 8 if case == "generated" else 16
+    assert W * B // (64 // packed) > 3072                 # the persistent launch was taken
     for k in ("models", "pred", "resid", "raw", "best_start"):
         assert np.array_equal(outs[0][k], outs[1][k], equal_nan=True), k
     for k in ("info_a", "info_b"):
