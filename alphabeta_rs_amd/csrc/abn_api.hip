@@ -1445,7 +1445,9 @@ static int plan_pairwise(abn_ctx* c, int n, long long L, PairPlan& pp) {
   // samples per block: 4 x 4 pairs per unit halve the LDS traffic per instruction but need enough samples to keep 256
   // threads busy (n = 15: ten 4 x 4 blocks against thirty-six 2 x 2 blocks)
   int bs = n >= 32 ? 4 : 2;
-  if (const char* e = getenv("ABN_PAIR_BLOCK")) bs = atoi(e) == 4 ? 4 : 2;  // measurement aid
+#ifdef ABN_MEASUREMENT_KNOBS  // scripts/pw_sweep.sh builds with this: block size, slices, grid and phase switches from the environment
+  if (const char* e = getenv("ABN_PAIR_BLOCK")) bs = atoi(e) == 4 ? 4 : 2;
+#endif
   pp.bs = bs;
   a.nb = (n + bs - 1) / bs;
   a.items = a.nb * (a.nb + 1) / 2;
@@ -1472,17 +1474,21 @@ static int plan_pairwise(abn_ctx* c, int n, long long L, PairPlan& pp) {
     // every unit ends with one LDS atomic per pair: stop at the first slicing that keeps 70 % of the thread-passes busy
     if ((double)units / (double)(passes * kPairThreads) >= 0.7) break;
   }
-  if (const char* e = getenv("ABN_PAIR_SLICES")) {  // measurement aid
+#ifdef ABN_MEASUREMENT_KNOBS
+  if (const char* e = getenv("ABN_PAIR_SLICES")) {
     const int sl = atoi(e);
     if (sl >= 1 && sl <= smax && (wt / 4) % sl == 0) S = sl;
   }
   if (const char* e = getenv("ABN_PAIR_DEBUG")) a.dbg = atoi(e);
+#endif
   a.S = S;
   a.units = a.items * S;
   a.ntiles = (L + 32ll * wt - 1) / (32ll * wt);
   const long long per_cu = std::max<long long>(1, std::min<long long>((160 * 1024) / (long long)pp.lds, bs == 4 ? 3 : 4));
   long long cu_blocks = per_cu;
-  if (const char* e = getenv("ABN_PAIR_GRID")) cu_blocks = std::max(1, atoi(e));  // measurement aid
+#ifdef ABN_MEASUREMENT_KNOBS
+  if (const char* e = getenv("ABN_PAIR_GRID")) cu_blocks = std::max(1, atoi(e));
+#endif
   pp.grid = (unsigned)std::max<long long>(1, std::min<long long>(a.ntiles, 256LL * cu_blocks));  // persistent workgroups
   pp.rows = a.red_in_lds ? (int)pp.grid : 1;
   pp.item_tab.clear();
