@@ -297,10 +297,14 @@ def stream_probe(A, ctx, seed, steps=2, every=5, B=8192, tag="C5 shard"):
 
 
 def stream_sweep(A, ctx, seed):
-    """the stream kernel with a co-resident working set far below and far above the Infinity Cache"""
-    return {"small_working_set": stream_probe(A, ctx, seed, steps=2, every=5, B=512, tag="C5 shard, 512 chains"),
-            "large_working_set": stream_probe(A, ctx, seed, steps=1, every=2, B=1024,
-                                              tag="deep pedigree sampled every 2nd generation")}
+    """The stream kernel with a co-resident working set far below and far above the 256 MiB Infinity Cache at a
+    comparable number of co-resident wavefronts (the LDS scratch per chain decides how many fit): shorter / longer rows
+    of the same deep pedigree.  If the large-working-set rate matches the standard probe's, that probe's stream comes
+    from DRAM; if it is lower, the difference is what the Infinity Cache served."""
+    return {"small_working_set": stream_probe(A, ctx, seed, steps=2, every=10, B=8192,
+                                              tag="deep pedigree sampled every 10th generation"),
+            "large_working_set": stream_probe(A, ctx, seed, steps=1, every=3, B=4096,
+                                              tag="deep pedigree sampled every 3rd generation")}
 
 
 def launch_ranks(args) -> int:
@@ -335,7 +339,11 @@ def launch_ranks(args) -> int:
     if any(codes):
         print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
         return next(c for c in codes if c) or 1
-    sys.stdout.write(out0)
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]   # the ONE JSON line; libraries may chat on stdout
+    if len(lines) != 1:
+        print(f"bench.py: rank 0 printed {len(lines)} JSON lines", file=sys.stderr)
+        return 1
+    print(lines[0])
     return 0
 
 
