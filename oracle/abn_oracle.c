@@ -10,6 +10,11 @@
  *     discriminated by any reference fixture (both variants reproduce every golden value); the fused
  *     form is used here and in the HIP kernel.
  *   - ndarray `var` uses mul_add (analysis only).
+ * The `lanes` argument of the cost / fit functions selects the residual summation order: 1 = the reference's serial
+ * order; G (<= 64) = G accumulators (rows l, l+G, ...) and an xor-butterfly 1, 2, 4, ...; G | 3 << 8 = four-row
+ * blocks (the stream kernels); 0x10040 = the canonical tree of the HIP path (64 accumulators, high lane bits first).
+ * Pinning: golden vectors and known answers of the reference's own tests (tests/test_oracle_golden.py) and the
+ * reference-held R outputs (tests/test_r_anchors.py); the argmin 0.8.1 trajectory itself is "parity unpinned".
  * Build: gcc -O2 -ffp-contract=off -fopenmp -fPIC -shared (see oracle/Makefile).
  */
 #pragma STDC FP_CONTRACT OFF
