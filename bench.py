@@ -362,6 +362,9 @@ def main():
                     help="skip the short C5-shard run that measures the stream-mode kernel against the HBM roof")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 ranks on one GPU)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="initialise the process group and run the gather even with one rank (exercises the "
+                         "torch.distributed / RCCL path on a one-GPU box)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the short extra workloads (C2, C4 shard, G351) and the PCIe-inclusive timing")
     ap.add_argument("--stream-sweep", action="store_true",
@@ -381,6 +384,12 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for a "
                          "different GPU count than asked for")
 
+    # stdout carries exactly ONE line, the JSON: libraries that chat on file descriptor 1 (RCCL prints a version banner,
+    # gloo its connection count) go to stderr until the result is printed
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -391,8 +400,10 @@ def main():
         raise SystemExit(f"LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible")
     local_rank = local_rank % ndev          # gloo rehearsal: several ranks may share one GPU
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import alphabeta_rs_amd as A
@@ -403,6 +414,8 @@ def main():
         ctx = A.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
         r = pairwise_bench(A, ctx, reps=max(3, args.steps))
         big = r["shapes"][-1]
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps({"metric": "pairwise divergence (DMatrix::from) code bytes/s", "value": big["achieved_GBps"],
                           "unit": "GB/s", "n_gpus": 1, "steps": max(3, args.steps), "warmup": 1,
                           "ms_per_step": big["kernel_ms_avg"], "higher_is_better": True, "scaling": "weak",
@@ -411,7 +424,8 @@ def main():
                                                  "codes resident in HBM"},
                           "roofline": {"bound": "hbm", "achieved": big["achieved_GBps"], "peak": HBM_PEAK_GBS,
                                        "unit": "GB/s", "frac": big["frac"], "traffic": None},
-                          "pairwise": r}))
+                          "pairwise": r}), flush=True)
+        os.dup2(2, 1)
         ctx.close()
         return
     wl = make_workload(args.workload, rank, world)
@@ -426,16 +440,16 @@ def main():
     # the bootstrap table lives in a torch tensor so that RCCL can gather it without a copy
     raw_local = torch.empty((Wr, B, 7), dtype=torch.float64, device="cuda")
     plan.bind_raw(raw_local.data_ptr())
-    raw_all = torch.empty((world * Wr, B, 7), dtype=torch.float64, device="cuda") if world > 1 else raw_local
+    raw_all = torch.empty((world * Wr, B, 7), dtype=torch.float64, device="cuda") if collective else raw_local
     plan.set_windows(wl["D"], wl["p0"])          # H2D + index-buffer generation: outside the timed region
 
     def step():
         plan.run()                               # phase A -> select -> phase B on torch's current stream
-        if world > 1:                            # (same stream: the collective is ordered after the kernels)
+        if collective:                           # (same stream: the collective is ordered after the kernels)
             dist.all_gather_into_tensor(raw_all.view(-1), raw_local.view(-1))
 
     def fence():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -459,7 +473,7 @@ def main():
         kms[k] /= max(1, args.steps)
     cnt = plan.counters()
     out = plan.download()
-    if world > 1:
+    if collective:
         # the gathered table must hold every rank's shard: compare per-rank checksums
         step()
         fence()
@@ -561,10 +575,13 @@ def main():
             if bs >= 0:
                 result["cpu_baseline"] = cpu_baseline(wl, out["models"][0], out["pred"][0], out["resid"][0], lanes, seed,
                                                       float(out["info_b"]["evals"][0].mean()))
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(result), flush=True)
+        os.dup2(2, 1)
     plan.close()
     ctx.close()
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 
