@@ -1030,9 +1030,24 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
     a.D = dst;
   }
   // few bootstraps: latency-bound like phase A -> the speculative kernel (four wavefronts per chain)
-  const bool spec = a.dmode == 1 && p->opt.lanes_per_chain == 0 && (long long)p->W * p->B <= spec_max_chains(p->N) &&
-                    spec_applicable(a);
-  int rc = spec ? launch_fit_spec(c, a, st) : launch_fit(c, a, p->lanes, st);
+  bool spec = a.dmode == 1 && p->opt.lanes_per_chain == 0 && (long long)p->W * p->B <= spec_max_chains(p->N) &&
+              spec_applicable(a);
+  int lanes_b = p->lanes;
+  // ... and up to 192 chains per packed lane (3072 for the 16-lane kernels) a wavefront per chain still beats packing
+  // several chains into one (scripts/b_kernel_sweep.py, C3 topology: 2000 bootstraps 1.36 ms against 1.74 ms packed and
+  // 1.81 ms speculative; 4000: 1.99 against 1.75; bundled 6-row pedigree, 8 lanes: 2000 bootstraps 1.98 against 1.90)
+  if (!spec && a.dmode == 1 && p->opt.lanes_per_chain == 0 && p->lanes < kWave &&
+      (long long)p->W * p->B <= 192LL * p->lanes && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree))
+    lanes_b = kWave;
+#ifdef ABN_MEASUREMENT_KNOBS  // ABN_PHASE_B_KERNEL = spec | wide | packed
+  if (const char* e = getenv("ABN_PHASE_B_KERNEL")) {
+    const bool can_wide = a.dmode == 1 && p->opt.lanes_per_chain == 0 && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree);
+    if (!strcmp(e, "spec")) spec = can_wide && spec_applicable(a);
+    if (!strcmp(e, "wide")) { spec = false; if (can_wide) lanes_b = kWave; }
+    if (!strcmp(e, "packed")) spec = false;
+  }
+#endif
+  int rc = spec ? launch_fit_spec(c, a, st) : launch_fit(c, a, lanes_b, st);
   if (rc) return rc;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[5], st));
   return ABN_OK;

@@ -39,10 +39,10 @@ CANON = 0x10040   # the canonical tree of every LDS-resident pedigree: 64 accumu
 @pytest.mark.parametrize("kind,tree", (("c3", CANON), ("generated", CANON), ("mid", CANON), ("golden351", CANON)))
 def test_results_do_not_depend_on_launch_size(abn, gpu_ctx, golden, oracle, kind, tree):
     """Auto options.  The same window fitted (1) alone — both phases on the four-wavefront speculative kernel —,
-    (2) among 200 windows — phase A one wavefront per chain, phase B packed / persistent —, and (3) among 800
-    windows — both phases packed — gives byte-identical models, residuals, bootstrap rows, iteration and evaluation
-    counts: the reduction tree is the pedigree's, whichever kernel a launch picks.  Window 0 is also checked
-    against the oracle."""
+    (2) among 50 windows — phase B (2000 bootstraps) one wavefront per chain —, (3) among 200 windows — phase A one
+    wavefront per chain, phase B packed / persistent —, and (4) among 800 windows — both phases packed — gives
+    byte-identical models, residuals, bootstrap rows, iteration and evaluation counts: the reduction tree is the
+    pedigree's, whichever kernel a launch picks.  Window 0 is also checked against the oracle."""
     ped, p0 = _pedigree(kind, golden)
     assert abn.reduction_tree(ped[:, :3]) == tree
     n = ped.shape[0]
@@ -50,7 +50,7 @@ def test_results_do_not_depend_on_launch_size(abn, gpu_ctx, golden, oracle, kind
     iters_a, iters_b = (300, 150) if n > 200 else (2000, 1000)
     o = abn.default_options(seed=seed, max_iters_start=iters_a, max_iters_boot=iters_b)
     outs = []
-    for W in (1, 200, 800):
+    for W in (1, 50, 200, 800):
         rng = np.random.default_rng(17)
         D = np.tile(ped[:, 3], (W, 1))
         if W > 1:                          # other windows differ; window 0 is the same data everywhere
@@ -67,8 +67,8 @@ def test_results_do_not_depend_on_launch_size(abn, gpu_ctx, golden, oracle, kind
             assert np.array_equal(out[k][0], outs[0][k][0], equal_nan=True), k
         for k in ("info_a", "info_b"):
             assert np.array_equal(out[k][0], outs[0][k][0]), k
-    # 200 and 800 windows share windows 1..199 as well
-    assert np.array_equal(outs[1]["raw"], outs[2]["raw"][:200])
+    # 50, 200 and 800 windows share their leading windows as well
+    assert np.array_equal(outs[1]["raw"], outs[2]["raw"][:50]) and np.array_equal(outs[2]["raw"], outs[3]["raw"][:200])
     s0 = abn.gen_start_simplices(seed, 0, S, ped[:, 3].max())
     fits = oracle.fit_batch(ped, p0, p0, 1.0, s0, iters_a, lanes=tree)
     k, model, pred, resid, _ = oracle.select_best(ped, p0, fits["best"])
