@@ -65,3 +65,18 @@ def test_integration_doc_lists_every_symbol():
     block = block[:block.index("\n}\n")]
     bound = sorted(set(re.findall(r"pub fn (abn_[a-z0-9_]+)\(", block)))
     assert bound == declared_symbols()
+
+
+def test_multi_device_entry_refuses_without_a_device(abn):
+    """abn_multi_* has no CPU fallback either: without a HIP device creation fails with ABN_ERR_NO_DEVICE; bad arguments
+    are status codes; librccl is found (the gather binds it at run time)."""
+    assert abn.rccl_available()
+    gens = np.array([[0.0, 1.0, 2.0], [0.0, 2.0, 2.0]])
+    if abn.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(abn.AbnError) as e:
+        abn.MultiPlan([0], gens, 1, 2, 2)
+    assert e.value.status == 3
+    L = abn.load_library()
+    h = ctypes.c_void_p()
+    assert L.abn_multi_create(None, 0, None, None, 0, 0, 0, 0, ctypes.byref(h)) == 1 and not h.value
