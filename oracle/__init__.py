@@ -19,6 +19,8 @@ import numpy as np
 
 _HERE = Path(__file__).resolve().parent
 _LIB_PATH = _HERE / "libabn_oracle.so"
+if os.environ.get("ABN_ORACLE_LIB"):  # tests/test_oracle_sanitizers.py: the address/UB-sanitizer build of the same source
+    _LIB_PATH = Path(os.environ["ABN_ORACLE_LIB"])
 
 FIT_CONVERGED, FIT_MAX_ITERS, FIT_NONFINITE, FIT_TARGET = 0, 1, 2, 3
 
