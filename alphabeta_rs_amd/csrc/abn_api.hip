@@ -21,12 +21,57 @@ using namespace abn;
 static_assert(sizeof(abn_fit_info) == sizeof(FitInfoDev), "abn_fit_info layout");
 
 // ------------------------------------------------------------------------------------------------
+// Device-buffer pool of a context.  The drop-in entry points (abn_ab_neutral_run, abn_boot_model_run, abn_cost_batch,
+// abn_fit_batch: one call per window in the reference's loops) build and drop a plan per call — seventeen hipMalloc /
+// hipFree pairs, several hundred microseconds next to a 1-3 ms fit.  Freed buffers of up to kPoolBufMax bytes are kept
+// (at most kPoolTotalMax in all) and handed out again, best fit within 2x; everything is stream-ordered on the
+// context's stream, and abn_shutdown frees the pool.
+constexpr size_t kPoolBufMax = (size_t)64 << 20, kPoolTotalMax = (size_t)256 << 20;
+struct BufPool {
+  std::vector<std::pair<void*, size_t>> free_list;
+  size_t held = 0;
+  void* take(size_t bytes, size_t* cap) {
+    size_t best = free_list.size();
+    for (size_t i = 0; i < free_list.size(); ++i)
+      if (free_list[i].second >= bytes && free_list[i].second <= 2 * bytes + 256 &&
+          (best == free_list.size() || free_list[i].second < free_list[best].second))
+        best = i;
+    if (best == free_list.size()) return nullptr;
+    void* p = free_list[best].first;
+    *cap = free_list[best].second;
+    held -= *cap;
+    free_list[best] = free_list.back();
+    free_list.pop_back();
+    return p;
+  }
+  bool give(void* p, size_t cap) {
+    if (cap > kPoolBufMax || held + cap > kPoolTotalMax) return false;
+    free_list.emplace_back(p, cap);
+    held += cap;
+    return true;
+  }
+  void clear() {
+    for (auto& e : free_list) (void)hipFree(e.first);
+    free_list.clear();
+    held = 0;
+  }
+};
+
 struct abn_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::vector<hipStream_t> side;  // lazily created: window groups of a plan run concurrently on these
+  BufPool pool;
   std::string err;
+};
+
+// the pool DevBuf allocations of the current call draw from (set by PoolScope around the entry points)
+static thread_local BufPool* g_pool = nullptr;
+struct PoolScope {
+  BufPool* prev;
+  explicit PoolScope(abn_ctx* c) : prev(g_pool) { g_pool = c ? &c->pool : nullptr; }
+  ~PoolScope() { g_pool = prev; }
 };
 
 static int set_err(abn_ctx* c, int status, const std::string& msg) {
@@ -45,20 +90,35 @@ template <class T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  size_t cap = 0;          // bytes of the allocation behind p
+  BufPool* pool = nullptr;  // where it came from / goes back to
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && !(pool && pool->give(p, cap))) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    cap = 0;
   }
   hipError_t alloc(size_t count) {
     release();
     if (count == 0) return hipSuccess;
-    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
-    if (e == hipSuccess) n = count;
+    const size_t bytes = count * sizeof(T);
+    pool = g_pool;
+    if (pool) {
+      if (void* q = pool->take(bytes, &cap)) {
+        p = (T*)q;
+        n = count;
+        return hipSuccess;
+      }
+    }
+    hipError_t e = hipMalloc((void**)&p, bytes);
+    if (e == hipSuccess) {
+      n = count;
+      cap = bytes;
+    }
     return e;
   }
   size_t bytes() const { return n * sizeof(T); }
@@ -408,6 +468,8 @@ extern "C" int abn_shutdown(abn_ctx* c) {
   if (!c) return ABN_ERR_INVALID_ARG;
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   for (auto st : c->side) (void)hipStreamDestroy(st);
+  (void)hipSetDevice(c->device);
+  c->pool.clear();
   delete c;
   return ABN_OK;
 }
@@ -487,6 +549,7 @@ extern "C" int abn_gen_boot_indices(abn_ctx* c, uint64_t seed, uint32_t window, 
   if (!c || !idx || nb < 0 || n_rows <= 0 || nb > 0x7fffffff) return ABN_ERR_INVALID_ARG;
   if (nb == 0) return ABN_OK;
   HIPCHK(c, hipSetDevice(c->device));
+  PoolScope pool_scope(c);
   DevBuf<uint32_t> d;
   HIPCHK(c, d.alloc((size_t)nb * (size_t)n_rows));
   int rc = launch_gen_idx(c, d.p, n_rows, (int)nb, 1, seed, window, b0);
@@ -509,6 +572,7 @@ extern "C" int abn_cost_batch(abn_ctx* c, const abn_options* opts, const double*
   if (m == 0) return ABN_OK;
   const abn_options o = resolve(opts);
   HIPCHK(c, hipSetDevice(c->device));
+  PoolScope pool_scope(c);
   Topology t;
   int rc = build_topology(pedigree, n_rows, 4, t);
   if (rc) return set_err(c, rc, abn_status_string(rc));
@@ -607,6 +671,7 @@ extern "C" int abn_fit_batch(abn_ctx* c, const abn_options* opts, const double* 
   if (const char* oe = options_error(o)) return set_err(c, ABN_ERR_INVALID_ARG, oe);
   if (max_iters < 0 || max_iters > (1 << 28)) return set_err(c, ABN_ERR_INVALID_ARG, "max_iters must be in 0 .. 2^28");
   HIPCHK(c, hipSetDevice(c->device));
+  PoolScope pool_scope(c);
   Topology t;
   int rc = build_topology(pedigree, n_rows, 4, t);
   if (rc) return set_err(c, rc, abn_status_string(rc));
@@ -736,6 +801,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
     if (const char* oe = options_error(o)) return set_err(c, ABN_ERR_INVALID_ARG, oe);
   }
   HIPCHK(c, hipSetDevice(c->device));
+  PoolScope pool_scope(c);
   abn_plan* p = new (std::nothrow) abn_plan();
   if (!p) return ABN_ERR_HIP;
   p->ctx = c;
@@ -843,6 +909,7 @@ extern "C" int abn_plan_set_window_ids(abn_plan* p, const uint32_t* ids) {
   abn_ctx* c = p->ctx;
   if (p->windows_set) return set_err(c, ABN_ERR_STATE, "abn_plan_set_window_ids must precede abn_plan_set_windows");
   HIPCHK(c, hipSetDevice(c->device));
+  PoolScope pool_scope(c);
   if (!ids) {
     p->wid_host.clear();
     p->wid.release();
@@ -1363,6 +1430,7 @@ extern "C" int abn_select_best(abn_ctx* c, const double* pedigree, int32_t n_row
   if (!pedigree || n_rows <= 0 || !models || n_models <= 0 || !best_index)
     return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
   HIPCHK(c, hipSetDevice(c->device));
+  PoolScope pool_scope(c);
   Topology t;
   int rc = build_topology(pedigree, n_rows, 4, t);
   if (rc) return set_err(c, rc, abn_status_string(rc));
@@ -1426,6 +1494,7 @@ extern "C" int abn_bootstrap_rows(abn_ctx* c, const double* best, int64_t n_boot
   if (!best || !raw || n_boot < 0) return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
   if (n_boot == 0) return ABN_OK;
   HIPCHK(c, hipSetDevice(c->device));
+  PoolScope pool_scope(c);
   DevBuf<double> db, dr;
   HIPCHK(c, db.alloc((size_t)n_boot * 4));
   HIPCHK(c, dr.alloc((size_t)n_boot * 7));
@@ -1573,6 +1642,7 @@ extern "C" int abn_pairwise_divergence_dev(abn_ctx* c, const void* dev_codes, in
   if (!dev_codes || n_samples <= 0 || n_sites < 0) return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
   if (n_samples < 2) return ABN_OK;
   HIPCHK(c, hipSetDevice(c->device));
+  PoolScope pool_scope(c);
   return pairwise_on_device(c, (const uint8_t*)dev_codes, n_samples, n_sites, (unsigned long long*)dev_diff,
                             (unsigned long long*)dev_both, (double*)dev_dvalue, kernel_ms);
 }
@@ -1584,6 +1654,7 @@ extern "C" int abn_pairwise_divergence(abn_ctx* c, const uint8_t* codes, int32_t
   const size_t n = (size_t)n_samples, npairs = n * (n - 1) / 2;
   if (npairs == 0) return ABN_OK;
   HIPCHK(c, hipSetDevice(c->device));
+  PoolScope pool_scope(c);
   DevBuf<uint8_t> dcodes;
   DevBuf<unsigned long long> ddiff, dboth;
   DevBuf<double> ddv;

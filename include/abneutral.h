@@ -92,6 +92,8 @@ int abn_device_count(int* count);
  * otherwise the given hipStream_t is borrowed (e.g. torch.cuda.current_stream().cuda_stream != 0). */
 #define ABN_STREAM_DEFAULT ((void*)(intptr_t)-1)
 int abn_init(int device_ordinal, void* stream, abn_ctx** ctx);
+/* Frees the context and its device-buffer pool (the per-call entry points recycle their device buffers through it
+ * instead of hipMalloc / hipFree per call).  Destroy the context's plans first. */
 int abn_shutdown(abn_ctx* ctx);
 const char* abn_last_error(const abn_ctx* ctx);
 const char* abn_status_string(int status);
