@@ -174,7 +174,7 @@ static int build_topology(const double* rows, int n, int stride, Topology& t) {
   t.T = tmax;
   t.TP = tmax + 1;
   t.KP = (t.K + 1) & ~1;
-  t.chain_stride = 9 * t.TP + t.KP + 4;  // power table, dt1t2 per triple, 4 per-chain constants
+  t.chain_stride = kPw * t.TP + t.KP + 4;  // power table, dt1t2 per triple, 4 per-chain constants
   return ABN_OK;
 }
 
@@ -283,7 +283,7 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
   int rmax = pick_rmax(a.N, lanes);
   // the reduction tree: the canonical one (any resident kernel) or one accumulator per lane
   if (a.tree != kTreeCanon) a.tree = lanes;
-  const int np = ((a.N + 1) & ~1) + ((a.K + 1) / 2);  // resident observations + this chain's triple list
+  const int np = ((a.N + 1) & ~1) + (((a.K + 1) / 2 + 1) & ~1);  // resident observations + this chain's triple list (even: 16-byte aligned chains)
   if (rmax > 0) {
     if ((size_t)ng * (size_t)(a.chain_stride + np) * sizeof(double) > kLdsResidentMax) rmax = 0;
     else a.chain_stride += np;
@@ -318,7 +318,7 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
 // true when launch_fit will use the stream variant for this pedigree / lane count
 static bool fit_streams(int n, int chain_stride, int lanes) {
   if (pick_rmax(n, lanes) == 0) return true;
-  const int np = ((n + 1) & ~1) + n / 2 + 1;  // observations + triple list (K <= n)
+  const int np = ((n + 1) & ~1) + n / 2 + 2;  // observations + triple list (K <= n)
   return (size_t)(kWave / lanes) * (size_t)(chain_stride + np) * sizeof(double) > kLdsResidentMax;
 }
 
@@ -337,7 +337,7 @@ static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree) {
   if (tree != kTreeCanon) return tree == kWave;
   const int rmax = pick_rmax(n_rows, kWave);
   if (rmax <= 0) return false;
-  const int np = ((n_rows + 1) & ~1) + n_rows / 2 + 1;
+  const int np = ((n_rows + 1) & ~1) + n_rows / 2 + 2;
   return (size_t)(chain_stride + np) * sizeof(double) <= kLdsResidentMax;
 }
 
@@ -1051,7 +1051,7 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   s.pred = p->pred.p + o * N;
   s.resid = p->resid.p + o * N;
   s.best_start = p->best_start.p + o;
-  const size_t lds = ((size_t)9 * a.TP + p->topo.KP + kSelChunk) * sizeof(double);
+  const size_t lds = ((size_t)kPw * a.TP + p->topo.KP + kSelChunk) * sizeof(double);
   if (timed) HIPCHK(c, hipEventRecord(p->ev[2], st));
   hipLaunchKernelGGL(abn_select_lse_kernel, dim3((unsigned)((long long)wn * p->S)), dim3(kWave), lds, st, s);
   hipLaunchKernelGGL(abn_select_kernel, dim3((unsigned)wn), dim3(kWave), lds, st, s);
@@ -1434,7 +1434,7 @@ extern "C" int abn_select_best(abn_ctx* c, const double* pedigree, int32_t n_row
   Topology t;
   int rc = build_topology(pedigree, n_rows, 4, t);
   if (rc) return set_err(c, rc, abn_status_string(rc));
-  const size_t lds = ((size_t)9 * t.TP + t.KP + kSelChunk) * sizeof(double);
+  const size_t lds = ((size_t)kPw * t.TP + t.KP + kSelChunk) * sizeof(double);
   if (lds > kMaxDynLds) return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS than supported");
   DevTopology dt;
   rc = upload_topology(c, t, dt);

@@ -10,7 +10,7 @@
 // One cost evaluation (Problem::cost, src/structs.rs:194-216) for candidate x = (alpha,beta,weight,c):
 //   P1  genmatrix(alpha,beta)                          src/divergence.rs:96-114      (all lanes)
 //   P2  power table G^0..G^T, left-accumulated         src/divergence.rs:16-31       (lane r<3 = row r)
-//       -> LDS, pw[k][9]
+//       -> LDS, pw[k][kPw]
 //   P3  per DISTINCT (t0,t1-t0,t2-t0) triple: dt1t2    src/divergence.rs:51-90       (lane per triple)
 //       -> LDS dt[K]   (rows sharing a triple share the value bit for bit)
 //   P4  per row: (D_i - c - dt[tid_i])^2 + penalty     src/structs.rs:208-213        (lane per row)
@@ -25,6 +25,7 @@
 namespace abn {
 
 constexpr int kWave = 64;
+constexpr int kPw = 10;  // doubles per entry of the power table in LDS: 9 elements + 1 so that entries are 16-byte aligned
 constexpr int kStreamVec = 4;  // consecutive rows per lane and block in stream mode
 #ifndef ABN_STREAM_BLOCKS
 #define ABN_STREAM_BLOCKS 6
@@ -40,6 +41,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint16_t u16x4 __attribute__((ext_vector_type(4), aligned(2)));
 typedef double f64x2 __attribute__((ext_vector_type(2), aligned(8)));
 typedef uint32_t u32x4_lds __attribute__((ext_vector_type(4)));  // naturally aligned: ds_read_b128
+typedef double f64x2_lds __attribute__((ext_vector_type(2)));    // naturally aligned: ds_read_b128
 
 // ---- fit states of the evaluation-synchronous Nelder-Mead machine
 constexpr int ST_INIT0 = 0;     // 0..4: evaluating start vertex k           (argmin Solver::init)
@@ -208,7 +210,10 @@ constexpr int kDppQuadBcast0 = 0x00, kDppQuadBcast1 = 0x55, kDppQuadBcast2 = 0xA
 
 // P2: the power table G^0..G^T, left-accumulated exactly as the reference (result = result.dot(matrix),
 // src/divergence.rs:25-30): every product element is fma(a_i2,b_2j, fma(a_i1,b_1j, fma(a_i0,b_0j, 0))) —
-// matrixmultiply's k-ascending FMA accumulation.  Table layout pw[k][9] (entry k at k*9, row r at +3r).
+// matrixmultiply's k-ascending FMA accumulation.  Table layout pw[k][kPw] (entry k at k*kPw, row r at +3r; element 9
+// is padding): entries are 16-byte aligned so that P3 reads a matrix with four ds_read_b128 and one ds_read_b64
+// (256 B/clk) — with a pitch of 9 doubles hipcc paired the reads into ds_read2_b64, which the LDS serves at half
+// that rate, and the LDS array, shared by the CU's wavefronts, was busy for most of a packed launch.
 //
 // G = 16, 32 (several chains per wavefront, throughput-bound): nine lanes of the group, lane 4i+j holds
 // element (i,j) of the running power; the three operands R[i][0..2] are the other lanes of the same quad
@@ -238,14 +243,14 @@ __device__ __forceinline__ void build_power_table(Gen Gm, int T, int TP, double*
       pe[0] = r;
       if (T >= 1) {
         r = i2 ? gc2 : (i1 ? gc1 : gc0);                      // matrix.clone(), :25  (G[i][j])
-        pe[9] = r;
-        double* pk = pe + 18;
+        pe[kPw] = r;
+        double* pk = pe + 2 * kPw;
         for (int k = 2; k <= T; ++k) {                        // :27-29 (hipcc does not unroll a loop of DPP
           const double b0 = dpp_mov<kDppQuadBcast0>(r), b1 = dpp_mov<kDppQuadBcast1>(r);  // operations with a run-time
           const double b2 = dpp_mov<kDppQuadBcast2>(r);                                     // trip count; by hand: no gain)
           r = fma3(b2, gc2, fma3(b1, gc1, fma3(b0, gc0, 0.0)));
           pk[0] = r;
-          pk += 9;
+          pk += kPw;
         }
       }
     }
@@ -260,10 +265,10 @@ __device__ __forceinline__ void build_power_table(Gen Gm, int T, int TP, double*
       r0 = is2 ? Gm.g6 : (is1 ? Gm.g3 : Gm.g0);  // matrix.clone(), :25
       r1 = is2 ? Gm.g7 : (is1 ? Gm.g4 : Gm.g1);
       r2 = is2 ? Gm.g8 : (is1 ? Gm.g5 : Gm.g2);
-      prow[9 + 0] = r0;
-      prow[9 + 1] = r1;
-      prow[9 + 2] = r2;
-      double* pk = prow + 18;
+      prow[kPw + 0] = r0;
+      prow[kPw + 1] = r1;
+      prow[kPw + 2] = r2;
+      double* pk = prow + 2 * kPw;
 #pragma unroll 2
       for (int k = 2; k <= T; ++k) {  // :27-29
         const double n0 = fma3(r2, Gm.g6, fma3(r1, Gm.g3, fma3(r0, Gm.g0, 0.0)));
@@ -275,7 +280,7 @@ __device__ __forceinline__ void build_power_table(Gen Gm, int T, int TP, double*
         pk[0] = r0;
         pk[1] = r1;
         pk[2] = r2;
-        pk += 9;
+        pk += kPw;
       }
     }
   }
@@ -344,7 +349,7 @@ __device__ __forceinline__ void build_power_table_mx(double al, double be, int T
     // nobody reads before it is rewritten: no store predicate in the loop
     const bool st = in3 && (c < NG);
     dst[h] = st ? lds0 + (size_t)c * chain_stride + 3 * x + y : dump;
-    step[h] = st ? 9 : 0;
+    step[h] = st ? kPw : 0;
     dst[h][0] = (x == y) ? 1.0 : 0.0;         // identity, :21-24
     dst[h] += step[h];
     if (T >= 1) dst[h][0] = B[h];             // matrix.clone(), :25
@@ -378,7 +383,7 @@ __device__ __forceinline__ void build_power_table_mx_pre(double A, double B, int
   const int x = lane & 3, blk = (lane >> 2) & 3, y = lane >> 4;
   const bool st = (x < 3) && (y < 3) && (blk == 0);
   double* dst = st ? pw + 3 * x + y : dump;
-  const int step = st ? 9 : 0;
+  const int step = st ? kPw : 0;
   dst[0] = (x == y) ? 1.0 : 0.0;              // identity, :21-24
   dst += step;
   if (T >= 1) dst[0] = B;                     // matrix.clone(), :25
@@ -400,26 +405,33 @@ __device__ __forceinline__ double cond_div(double a0, double a1, double a2, doub
   return 0.5 * (a0 * b1 + a1 * b0 + a1 * b2 + a2 * b1) + (a0 * b2 + a2 * b0);
 }
 
+// one table entry (16-byte aligned: kPw is even and so is every chain's LDS stride)
+__device__ __forceinline__ void load_matrix(const double* m, double (&M)[9]) {
+  const f64x2_lds* v = reinterpret_cast<const f64x2_lds*>(m);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const f64x2_lds x = v[e];
+    M[2 * e] = x[0];
+    M[2 * e + 1] = x[1];
+  }
+  M[8] = m[8];
+}
+
 // P3 for one distinct triple, src/divergence.rs:52-89.  Two load batches (G^t0, then G^a and G^b) with a
 // scheduling barrier in between keep the live registers of the fit kernel under 128 (4 wavefronts per SIMD).
 __device__ __forceinline__ double triple_dt(uint32_t tr, const double* pw, int TP, double sv0, double sv1,
                                             double sv2) {
   (void)TP;
   const int t0 = tr & 0xff, ea = (tr >> 8) & 0xff, eb = (tr >> 16) & 0xff;
-  double P[9];
-#pragma unroll
-  for (int e = 0; e < 9; ++e) P[e] = pw[t0 * 9 + e];  // pitch 9 doubles = 18 banks: 32 distinct exponents never conflict
+  double P[9], A[9], B[9];
+  load_matrix(pw + t0 * kPw, P);
   // svt0 = sv_gzero.t().dot(G^t0), :55
   const double s0 = fma3(sv2, P[6], fma3(sv1, P[3], fma3(sv0, P[0], 0.0)));
   const double s1 = fma3(sv2, P[7], fma3(sv1, P[4], fma3(sv0, P[1], 0.0)));
   const double s2 = fma3(sv2, P[8], fma3(sv1, P[5], fma3(sv0, P[2], 0.0)));
   __builtin_amdgcn_sched_barrier(0);
-  double A[9], B[9];
-#pragma unroll
-  for (int e = 0; e < 9; ++e) {
-    A[e] = pw[ea * 9 + e];
-    B[e] = pw[eb * 9 + e];
-  }
+  load_matrix(pw + ea * kPw, A);
+  load_matrix(pw + eb * kPw, B);
   const double d_mm = cond_div(A[6], A[7], A[8], B[6], B[7], B[8]);  // :68-73
   const double d_um = cond_div(A[3], A[4], A[5], B[3], B[4], B[5]);  // :75-80
   const double d_uu = cond_div(A[0], A[1], A[2], B[0], B[1], B[2]);  // :82-87
@@ -544,7 +556,7 @@ __device__ __forceinline__ double tree64_finish(const double (&acc)[kWave / G]) 
 // triples and its rows' triple ids in registers; an evaluation touches no global memory.
 // RMAX == 0 ("stream"): for larger pedigrees the rows are re-read every evaluation (bootstrap: the u32
 // index row is re-streamed from HBM, coalesced).
-// LDS per workgroup: 64/G chains x (9(T+1) + KP + 4 [+ NP]) doubles.
+// LDS per workgroup: 64/G chains x (kPw (T+1) + KP + 4 [+ NP]) doubles.
 // ------------------------------------------------------------------------------------------------
 template <int G, int RMAX, bool TWOPASS = false>
 __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)) void abn_fit_kernel(const FitArgs a) {
@@ -576,7 +588,7 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
   const int N = a.N, K = a.K, TP = a.TP;
 
   double* pw = lds + (size_t)g * a.chain_stride;
-  double* dtab = pw + 9 * TP;
+  double* dtab = pw + kPw * TP;
   double* wconst = dtab + ((K + 1) & ~1);                                 // p0uu, p0mm, eqp, eqp_weight*N
   double* dobs = wconst + 4;                                              // resident mode: N doubles
 
@@ -1036,7 +1048,7 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
   const int N = a.N, K = a.K, TP = a.TP;
 
   double* pw = lds + (size_t)g * a.chain_stride;
-  double* dtab = pw + 9 * TP;
+  double* dtab = pw + kPw * TP;
   double* wconst = dtab + ((K + 1) & ~1);                                 // p0uu, p0mm, eqp, eqp_weight*N
   double* dobs = wconst + 4;                                              // N doubles
   uint32_t* tri_s = reinterpret_cast<uint32_t*>(dobs + ((N + 1) & ~1));  // this group's copy of the triple list
@@ -1371,7 +1383,7 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
   const int N = a.N, K = a.K, TP = a.TP;
 
   double* pw = lds + (size_t)(keeper ? 0 : wv) * a.chain_stride;  // the keeper never touches its alias
-  double* dtab = pw + 9 * TP;
+  double* dtab = pw + kPw * TP;
   double* wconst = dtab + ((K + 1) & ~1);
   double* dobs = wconst + 4;
   double* xch = lds + (size_t)3 * a.chain_stride;  // two buffers of 3 costs (+ pad)
@@ -1894,7 +1906,7 @@ __global__ __launch_bounds__(kWave) void abn_select_lse_kernel(const SelectArgs 
   const int w = blockIdx.x / a.S, sidx = blockIdx.x - w * a.S;
   const int N = a.N;
   double* pw = lds;
-  double* dtab = pw + 9 * a.TP;
+  double* dtab = pw + kPw * a.TP;
   double* term = dtab + ((a.K + 1) & ~1);
   const size_t wN = (size_t)w * (size_t)N;
   double x[4];
@@ -1923,7 +1935,7 @@ __global__ __launch_bounds__(kWave) void abn_select_kernel(const SelectArgs a) {
   const int w = blockIdx.x;
   const int N = a.N;
   double* pw = lds;
-  double* dtab = pw + 9 * a.TP;
+  double* dtab = pw + kPw * a.TP;
   const size_t wN = (size_t)w * (size_t)N;
 
   int best = -1;
@@ -1994,7 +2006,7 @@ __global__ __launch_bounds__(kWave) void abn_cost_kernel(const CostArgs a) {
   const long long m = valid ? m_raw : 0;
   const int N = a.N, K = a.K, TP = a.TP;
   double* pw = lds + (size_t)g * a.chain_stride;
-  double* dtab = pw + 9 * TP;
+  double* dtab = pw + kPw * TP;
   double* term = lds + (size_t)NG * a.chain_stride;  // strict mode only (G == 64)
 
   const double al = a.cand[4 * m + 0], be = a.cand[4 * m + 1], wt = a.cand[4 * m + 2], ic = a.cand[4 * m + 3];
