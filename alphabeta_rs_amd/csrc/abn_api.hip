@@ -275,7 +275,8 @@ static hipError_t launch_fit_g(const FitArgs& a, int rmax, dim3 grid, size_t lds
   return twopass ? launch_fit_gt<G, true>(a, rmax, grid, lds, s) : launch_fit_gt<G, false>(a, rmax, grid, lds, s);
 }
 
-// `a.chain_stride` must be the topology's scratch stride (9*TP + KP + 4); the resident variant adds N doubles.
+// `a.chain_stride` must be the topology's scratch stride (kPw*TP + KP + 4, even); the resident variant adds an even
+// number of doubles (observations + triple list): every chain's region stays 16-byte aligned for load_matrix.
 static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
   const long long chains = (long long)a.W * a.C;
   if (chains <= 0) return ABN_OK;

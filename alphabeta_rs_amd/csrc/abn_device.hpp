@@ -26,6 +26,7 @@ namespace abn {
 
 constexpr int kWave = 64;
 constexpr int kPw = 10;  // doubles per entry of the power table in LDS: 9 elements + 1 so that entries are 16-byte aligned
+static_assert(kPw % 2 == 0 && kPw >= 9, "load_matrix reads 16-byte aligned pairs");
 constexpr int kStreamVec = 4;  // consecutive rows per lane and block in stream mode
 #ifndef ABN_STREAM_BLOCKS
 #define ABN_STREAM_BLOCKS 6
@@ -65,7 +66,7 @@ struct FitArgs {
   const uint32_t* tri;   // [K] t0 | (t1-t0)<<8 | (t2-t0)<<16
   const uint16_t* tid;   // [N] row -> triple
   int N, K, T, TP;       // TP = table pitch (>= T+1)
-  int chain_stride;      // doubles of LDS per chain: 9*TP + KP
+  int chain_stride;      // doubles of LDS per chain (even): kPw*TP + KP + ...
   // per-window data; wstride = 0 broadcasts window 0's scalars to every chain
   const double* p_uu;    // [W] p0uu
   const double* eqp;     // [W]

@@ -6,6 +6,10 @@ tag=${1:-r02}
 out=gpurun_out/$tag
 mkdir -p $out
 echo "== gpu tests"; timeout -k 10 900 python -m pytest tests -m gpu -q > $out/pytest.log 2>&1; tail -3 $out/pytest.log
+# profiles first: the bench line takes roofline.traffic only from a PMC profile of these very kernel sources
+echo "== rocprofv3: c3"; bash scripts/profile_round.sh $tag c3 > $out/profile_c3.log 2>&1; tail -2 $out/profile_c3.log
+echo "== rocprofv3: c5s"; bash scripts/profile_round.sh $tag c5s > $out/profile_c5s.log 2>&1; tail -2 $out/profile_c5s.log
+cp gpurun_out/profiles_c3/${tag}_* gpurun_out/profiles_c5s/${tag}_* profiles/ 2>/dev/null
 echo "== default bench line (C3, cpu baseline, stream probe, extras)"
 timeout -k 10 600 python bench.py > $out/bench_c3.json 2> $out/bench_c3.err; echo "rc=$?"
 for wl in c2 c4 g351 mp c5s pw; do
@@ -16,7 +20,5 @@ timeout -k 10 600 python bench.py --gpus 2 --backend gloo --steps 10 --no-extras
 timeout -k 10 300 python bench.py --gpus 2 --steps 2 > $out/bench_gpus2_nccl.out 2> $out/bench_gpus2_nccl.err; echo "nccl --gpus 2 on a one-GPU box: rc=$? (must be non-zero, no JSON)"
 echo "== stream-mode working-set sweep"
 timeout -k 10 900 python bench.py --stream-sweep --no-extras --no-cpu-baseline --steps 5 > $out/bench_stream_sweep.json 2> $out/bench_stream_sweep.err; echo "rc=$?"
-echo "== rocprofv3: c3"; bash scripts/profile_round.sh $tag c3 > $out/profile_c3.log 2>&1; tail -2 $out/profile_c3.log
-echo "== rocprofv3: c5s"; bash scripts/profile_round.sh $tag c5s > $out/profile_c5s.log 2>&1; tail -2 $out/profile_c5s.log
 echo "== rocprofv3: pairwise"; bash scripts/pw_profile.sh $out/pw_prof > $out/pw_profile.txt 2>&1; cat $out/pw_profile.txt
 echo done
