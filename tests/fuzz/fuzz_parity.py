@@ -36,7 +36,12 @@ def main(seconds=120, seed=0):
             s0[0, int(rng.integers(0, 5)), int(rng.integers(0, 4))] = np.nan
         o = A.default_options(lanes_per_chain=lanes, shrink_on_failed_contraction=variant)
         eqp, ew = float(rng.uniform(0.3, 0.9)), float(rng.choice([0.0, 0.7, 1.0]))
-        best, info = ctx.fit_batch(ped, p0, eqp, ew, s0, iters, options=o)
+        try:
+            best, info = ctx.fit_batch(ped, p0, eqp, ew, s0, iters, options=o)
+        except A.AbnError as e:                            # explicit lane count x many generations x many triples
+            if "more LDS per workgroup" in str(e) and lanes in (8, 16, 32):
+                continue
+            raise
         code = int(info["lanes"][0])
         want = O.fit_batch(ped, p0, eqp, ew, s0, iters, shrink_variant=variant, lanes=code)
         ok = (np.array_equal(info["status"], want["status"]) and np.array_equal(info["iters"], want["iters"])
