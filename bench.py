@@ -30,6 +30,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_VALU_PEAK_TFLOPS = 78.6  # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+N_SIMDS, CLOCK_HZ = 256 * 4, 2.4e9   # MI355X: 256 CUs x 4 SIMDs; the clock the FP64 vector peak is quoted at
 
 
 def make_workload(name: str, rank: int, world: int):
@@ -171,7 +172,8 @@ def measured_traffic(workload: str):
             continue
         if j.get("workload") == workload and j.get("source_sha1") == sha:
             return j.get("hbm_bytes_per_launch"), {"file": f"profiles/{f.name}", "source_sha1": sha,
-                                                   "kernel": j.get("kernel"), "collected": j.get("collected")}
+                                                   "kernel": j.get("kernel"), "collected": j.get("collected"),
+                                                   "sq_insts_valu_per_launch": j.get("sq_insts_valu_per_launch")}
     return None, {"note": "no rocprofv3 PMC profile of this build's kernel sources under profiles/ "
                           f"(source_sha1 {sha[:12]}); run scripts/profile_round.sh", "source_sha1": sha}
 
@@ -545,6 +547,15 @@ def main():
             "valu_fp64": {"achieved_tflops": valu_tflops, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                           "frac": valu_tflops / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": flops_eval},
         }
+        # how busy the vector pipe is: wavefront vector instructions of the launch (SQ_INSTS_VALU of the stamped PMC
+        # profile) x 4 issue cycles against SIMDs x clock x launch time.  The roof the resident kernel actually runs
+        # under: with three wavefronts on a SIMD it is ~90 % busy; the launch average includes the tail of long chains.
+        nv = traffic_source.pop("sq_insts_valu_per_launch", None)
+        if nv and not stream:
+            peak = N_SIMDS * CLOCK_HZ / 4.0
+            roofline["valu_issue"] = {"insts_per_launch": nv, "achieved_ginst_per_s": nv / kern_s / 1e9,
+                                      "peak_ginst_per_s": peak / 1e9, "frac": nv / kern_s / peak,
+                                      "what": "wavefront vector instructions / s against 1024 SIMDs x 2.4 GHz / 4"}
         result = {
             "metric": "ABneutral model fits/sec (pedigree x bootstraps x windows)",
             "value": fits_per_s, "unit": "fits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

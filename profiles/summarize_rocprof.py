@@ -61,7 +61,10 @@ if big:
                 h.update(f.read_bytes())
         (out / f"{tag.split('_')[0]}_pmc_fit_boot_{workload}.json").write_text(json.dumps(
             {"workload": workload, "kernel": b, "FETCH_SIZE_KiB": p["FETCH_SIZE"], "WRITE_SIZE_KiB": p["WRITE_SIZE"],
-             "hbm_bytes_per_launch": hbm, "source_sha1": h.hexdigest(),
+             "hbm_bytes_per_launch": hbm,
+             # wavefront-instruction counts of the same launch (SQ pass): the vector pipe issues one per SIMD every 4 cycles
+             **{k.lower() + "_per_launch": p[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES") if k in p},
+             "source_sha1": h.hexdigest(),
              "collected": datetime.date.today().isoformat()}, indent=1))
 (out / f"{tag}_rocprof_summary.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps(summary, indent=1))
