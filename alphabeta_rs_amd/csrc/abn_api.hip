@@ -195,7 +195,14 @@ static int upload_topology(abn_ctx* c, const Topology& t, DevTopology& d) {
 // ------------------------------------------------------------------------------------------------
 // launch configuration
 // ------------------------------------------------------------------------------------------------
-constexpr size_t kMaxDynLds = 64 * 1024;
+constexpr size_t kDefaultDynLds = 64 * 1024;   // what a launch may ask for without opting in
+constexpr size_t kMaxDynLds = 160 * 1024;      // gfx950: the whole LDS of a CU, for the one-chain-per-workgroup kernels
+// A workgroup with one chain (stream-mode fits, selection, 64-lane cost) may need more than 64 KiB for pedigrees with
+// thousands of distinct triples: opt the kernel in (hipFuncAttributeMaxDynamicSharedMemorySize) before such a launch.
+static hipError_t allow_lds(const void* kernel, size_t lds) {
+  if (lds <= kDefaultDynLds) return hipSuccess;
+  return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
 constexpr size_t kLdsResidentMax = 40 * 1024;
 #ifndef ABN_PERSIST_WAVES
 #define ABN_PERSIST_WAVES 3072
@@ -253,8 +260,14 @@ static hipError_t launch_fit_gt(const FitArgs& a, int rmax, dim3 grid, size_t ld
     case 16:  // one wavefront per chain only (pick_rmax)
       hipLaunchKernelGGL((abn_fit_kernel<64, 16, TP>), grid, dim3(kWave), lds, s, a);
       break;
-    case -1: hipLaunchKernelGGL((abn_fit_kernel<G, -1, TP>), grid, dim3(kWave), lds, s, a); break;
-    default: hipLaunchKernelGGL((abn_fit_kernel<G, 0, TP>), grid, dim3(kWave), lds, s, a); break;
+    case -1:
+      if (hipError_t e = allow_lds(reinterpret_cast<const void*>(&abn_fit_kernel<G, -1, TP>), lds)) return e;
+      hipLaunchKernelGGL((abn_fit_kernel<G, -1, TP>), grid, dim3(kWave), lds, s, a);
+      break;
+    default:
+      if (hipError_t e = allow_lds(reinterpret_cast<const void*>(&abn_fit_kernel<G, 0, TP>), lds)) return e;
+      hipLaunchKernelGGL((abn_fit_kernel<G, 0, TP>), grid, dim3(kWave), lds, s, a);
+      break;
   }
   return hipGetLastError();
 }
@@ -294,7 +307,7 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
   // stream mode: rows shorter than one trip of the deep loop (kStreamBlocks x 4 rows x lanes) use the pair-loop variant
   if (rmax == 0 && a.N < 2 * kStreamBlocks * kStreamVec * lanes) rmax = -1;
   const size_t lds = (size_t)ng * (size_t)a.chain_stride * sizeof(double);
-  if (lds > kMaxDynLds)
+  if (lds > (lanes == kWave ? kMaxDynLds : kDefaultDynLds))
     return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS per workgroup than supported (T or K too large)");
   long long blocks = (chains + ng - 1) / ng;
   if (blocks > 0x7fffffffLL || chains > 0x7fffffffLL)
@@ -640,7 +653,9 @@ extern "C" int abn_cost_batch(abn_ctx* c, const abn_options* opts, const double*
   a.dt = ddt.p;
   a.puu = dpuu.p;
   size_t lds = ((size_t)ng * t.chain_stride + (o.strict_order ? kSelChunk : 0)) * sizeof(double);
-  if (lds > kMaxDynLds) return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS than supported");
+  if (lds > (lanes == kWave ? kMaxDynLds : kDefaultDynLds))
+    return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS than supported");
+  if (lanes == kWave) HIPCHK(c, allow_lds(reinterpret_cast<const void*>(&abn_cost_kernel<64>), lds));
   const long long blocks = (m + ng - 1) / ng;
   if (blocks > 0x7fffffffLL) return set_err(c, ABN_ERR_INVALID_ARG, "too many candidates");
   dim3 grid((unsigned)blocks);
@@ -831,7 +846,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   if (p->opt.lanes_per_chain == 0 && (long long)n_windows * n_starts <= kPhaseAWideMax &&
       tree_on_wave_ok(n_rows, p->topo.chain_stride, p->tree))
     p->lanes_a = 64;
-  if ((size_t)(kWave / p->lanes) * p->topo.chain_stride * sizeof(double) > kMaxDynLds ||
+  if ((size_t)(kWave / p->lanes) * p->topo.chain_stride * sizeof(double) > (p->lanes == kWave ? kMaxDynLds : kDefaultDynLds) ||
       ((size_t)p->topo.chain_stride + kSelChunk) * sizeof(double) > kMaxDynLds) {
     delete p;
     return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS per workgroup than supported (T or K too large)");
@@ -1054,6 +1069,8 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   s.best_start = p->best_start.p + o;
   const size_t lds = ((size_t)kPw * a.TP + p->topo.KP + kSelChunk) * sizeof(double);
   if (timed) HIPCHK(c, hipEventRecord(p->ev[2], st));
+  HIPCHK(c, allow_lds(reinterpret_cast<const void*>(&abn_select_lse_kernel), lds));
+  HIPCHK(c, allow_lds(reinterpret_cast<const void*>(&abn_select_kernel), lds));
   hipLaunchKernelGGL(abn_select_lse_kernel, dim3((unsigned)((long long)wn * p->S)), dim3(kWave), lds, st, s);
   hipLaunchKernelGGL(abn_select_kernel, dim3((unsigned)wn), dim3(kWave), lds, st, s);
   HIPCHK(c, hipGetLastError());
@@ -1477,6 +1494,8 @@ extern "C" int abn_select_best(abn_ctx* c, const double* pedigree, int32_t n_row
   a.pred = dpred.p;
   a.resid = dresid.p;
   a.best_start = dbest.p;
+  HIPCHK(c, allow_lds(reinterpret_cast<const void*>(&abn_select_lse_kernel), lds));
+  HIPCHK(c, allow_lds(reinterpret_cast<const void*>(&abn_select_kernel), lds));
   hipLaunchKernelGGL(abn_select_lse_kernel, dim3((unsigned)a.S), dim3(kWave), lds, c->stream, a);
   hipLaunchKernelGGL(abn_select_kernel, dim3(1), dim3(kWave), lds, c->stream, a);
   HIPCHK(c, hipGetLastError());

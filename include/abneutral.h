@@ -30,7 +30,10 @@ extern "C" {
 
 typedef enum abn_status {
   ABN_OK = 0,
-  ABN_ERR_INVALID_ARG = 1,   /* null pointer, non-positive size, unsupported option value            */
+  ABN_ERR_INVALID_ARG = 1,   /* null pointer, non-positive size, unsupported option value; also a pedigree
+                                whose power table and distinct-triple list (10 (T+1) + K + 4 doubles per chain) do
+                                not fit the 160 KiB of LDS a workgroup can have: K up to ~17 000 distinct triples
+                                at T = 255 (64 KiB per workgroup with an explicit lanes_per_chain below 64)          */
   ABN_ERR_BAD_PEDIGREE = 2,  /* a generation outside 0..127 after the `as i8` cast, or t1/t2 < t0      */
   ABN_ERR_NO_DEVICE = 3,     /* no usable HIP device (the product path never falls back to the CPU)    */
   ABN_ERR_HIP = 4,           /* a HIP runtime call failed; see abn_last_error()                        */

@@ -408,6 +408,45 @@ def test_deep_pedigree_stream_mode_c5_shape(abn, gpu_ctx, oracle, stream_mode):
     plan.close()
 
 
+def test_many_distinct_triples_need_more_than_64k_of_lds(abn, gpu_ctx, oracle):
+    """Maximum sizes: a pedigree with ~8 900 distinct (t0, t1-t0, t2-t0) triples over 40 generations needs
+    10 (T+1) + K + 4 doubles = 72 KiB of LDS per chain — more than a launch gets without opting in; the
+    one-chain-per-workgroup kernels (stream-mode fit, selection, 64-lane cost) opt in up to the CU's 160 KiB.
+    Cost, fits, selection and bootstraps bit-equal to the oracle."""
+    rng = np.random.default_rng(77)
+    n, tmax = 12000, 40
+    t0 = rng.integers(0, tmax // 2 + 1, n)
+    t1 = t0 + rng.integers(0, tmax - t0 + 1)
+    t2 = t0 + rng.integers(0, tmax - t0 + 1)
+    d = np.abs(rng.normal(0.02, 0.006, n))
+    ped = np.stack([t0, t1, t2, d], axis=1).astype(np.float64)
+    k_distinct = len({(a, b, c) for a, b, c in zip(t0, t1 - t0, t2 - t0)})
+    assert (10 * (tmax + 1) + k_distinct + 4) * 8 > 64 * 1024, k_distinct
+    p0 = 0.8
+    cand = np.array([[1e-3, 2e-3, 0.6, 0.01], [5e-4, 5e-4, 0.9, 0.0]])
+    cost, dt = gpu_ctx.cost_batch(ped, p0, p0, 1.0, cand, want_dt=True)
+    tree = abn.reduction_tree(ped[:, :3])
+    assert np.array_equal(cost, np.array([oracle.cost(ped, p0, p0, 1.0, x, lanes=tree) for x in cand]))
+    assert np.array_equal(dt[0], oracle.divergence(ped, 1 - p0, p0, *cand[0, :3])[0])
+    seed = 5
+    o = abn.default_options(seed=seed, max_iters_start=25, max_iters_boot=15)
+    plan = abn.Plan(gpu_ctx, ped[:, :3], 1, 2, 3, options=o)
+    plan.set_windows(ped[:, 3][None, :], np.array([p0]))
+    plan.run()
+    out = plan.download()
+    la, lb = int(out["info_a"]["lanes"][0, 0]), int(out["info_b"]["lanes"][0, 0])
+    s0 = abn.gen_start_simplices(seed, 0, 2, ped[:, 3].max())
+    fits = oracle.fit_batch(ped, p0, p0, 1.0, s0, 25, lanes=la)
+    assert np.array_equal(out["info_a"]["evals"][0], fits["evals"])
+    k, model, pred, resid, _ = oracle.select_best(ped, p0, fits["best"])
+    assert out["best_start"][0] == k and np.array_equal(out["models"][0], model)
+    assert np.array_equal(out["pred"][0], pred) and np.array_equal(out["resid"][0], resid)
+    wraw, wres = oracle.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, 3, max_iters=15, lanes=lb)
+    assert np.array_equal(out["raw"][0], wraw)
+    assert np.array_equal(out["info_b"]["evals"][0], wres["evals"])
+    plan.close()
+
+
 # ------------------------------------------------------------------------------------------------ edge cases
 def test_edge_cases_tiny_and_degenerate_pedigrees(abn, gpu_ctx, oracle):
     """Smallest inputs and degenerate generations: one row, one start, one bootstrap; all generations 0
