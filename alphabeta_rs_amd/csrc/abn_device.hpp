@@ -2327,9 +2327,11 @@ __global__ __launch_bounds__(kPairThreads, BS == 2 ? 4 : 3) void abn_pairwise_bi
 }
 
 // partial[rows][cols = 2 * npairs] -> diff[p], both[p], dvalue[p] = diff / (2 both) in f64 (:257; 0/0 = NaN like the
-// reference); any of the three may be null.  A workgroup owns 64 columns (32 pairs): 16 row groups of 64 threads sum
-// their rows (512-byte coalesced reads, eight in flight per thread), LDS combines the groups.  No atomics.
-constexpr int kPairReduceCols = 64, kPairReduceGroups = 16;
+// reference); any of the three may be null.  A workgroup owns 16 columns (8 pairs): 64 row groups of 16 threads sum
+// their rows (128-byte coalesced reads, eight in flight per thread), LDS combines the groups.  No atomics.  (Narrow
+// column blocks on purpose: 1225 pairs are 154 workgroups; with 64 columns each the 39 workgroups of that shape left
+// most of the chip idle, 8.1 us for 15 MB.)
+constexpr int kPairReduceCols = 16, kPairReduceGroups = 64;
 __global__ __launch_bounds__(kPairReduceCols * kPairReduceGroups) void abn_pairwise_reduce_kernel(
     const unsigned long long* partial, int rows, int cols, unsigned long long* diff, unsigned long long* both,
     double* dvalue) {
@@ -2343,10 +2345,15 @@ __global__ __launch_bounds__(kPairReduceCols * kPairReduceGroups) void abn_pairw
   }
   part[g][cx] = acc;
   __syncthreads();
+  // fold the row groups: 64 -> 8 rows in parallel, the last eight by the writing thread
+  for (int half = kPairReduceGroups / 2; half >= 8; half >>= 1) {
+    if (g < half) part[g][cx] += part[g + half][cx];
+    __syncthreads();
+  }
   if (g == 0 && c < cols && (cx & 1) == 0) {
     unsigned long long d = 0, cc = 0;
 #pragma unroll
-    for (int k = 0; k < kPairReduceGroups; ++k) {
+    for (int k = 0; k < 8; ++k) {
       d += part[k][cx];
       cc += part[k][cx + 1];
     }

@@ -20,6 +20,7 @@ def main(seconds=120, seed=0):
     rng = np.random.default_rng(seed)
     t_end = time.time() + seconds
     cases = fails = 0
+    t_note = time.time()
     while time.time() < t_end:
         n = int(rng.choice([1, 2, 5, 17, 64, 65, 105, 129, 300, 513, 700]))
         tmax = int(rng.choice([0, 1, 3, 8, 20, 40]))
@@ -50,6 +51,9 @@ def main(seconds=120, seed=0):
         ok = ok and np.array_equal(best[good], want["best"][good], equal_nan=True)
         ok = ok and np.array_equal(info["best_cost"][good], want["best_cost"][good], equal_nan=True)
         cases += 1
+        if time.time() - t_note > 60:                     # a sign of life for the GPU box's silence guard
+            t_note = time.time()
+            print(f"... {cases} cases, {fails} mismatches so far", flush=True)
         if not ok:
             fails += 1
             print("MISMATCH", dict(n=n, tmax=tmax, lanes=lanes, code=code, variant=variant, f=f, iters=iters, ew=ew),

@@ -14,6 +14,7 @@ def main(seconds=180, seed=0):
     rng = np.random.default_rng(seed)
     t_end = time.time() + seconds
     cases = fails = 0
+    t_note = time.time()
     while time.time() < t_end:
         n = int(rng.choice([3, 6, 40, 105, 200, 600]))
         tmax = int(rng.choice([1, 4, 8, 16]))
@@ -54,6 +55,9 @@ def main(seconds=180, seed=0):
                                           shrink_variant=variant, lanes=lb)
                 ok = ok and np.array_equal(out["raw"][w], wraw, equal_nan=True) and np.array_equal(out["info_b"]["evals"][w], wres["evals"])
         cases += 1
+        if time.time() - t_note > 60:                     # a sign of life for the GPU box's silence guard
+            t_note = time.time()
+            print(f"... {cases} cases, {fails} mismatches so far", flush=True)
         if not ok:
             fails += 1
             print("MISMATCH", dict(n=n, tmax=tmax, W=W, S=S, B=B, variant=variant, la=la, lb=lb, mi_a=mi_a), flush=True)
