@@ -50,6 +50,7 @@ EXPORTED_SYMBOLS = [
     "abn_multi_create", "abn_multi_destroy", "abn_multi_last_error", "abn_multi_set_windows", "abn_multi_run",
     "abn_multi_sync", "abn_multi_shard", "abn_multi_raw_device_ptr", "abn_multi_download", "abn_multi_counters",
     "abn_multi_rccl_available", "abn_reduction_tree", "abn_pairwise_divergence_dev", "abn_multi_set_window_ids",
+    "abn_multi_plan_shard",
 ]
 
 
@@ -144,6 +145,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     L.abn_multi_run.argtypes = [vp]
     L.abn_multi_sync.argtypes = [vp]
     L.abn_multi_shard.argtypes = [vp, C.c_int32, i32p]
+    L.abn_multi_plan_shard.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p]
     L.abn_multi_raw_device_ptr.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     L.abn_multi_download.argtypes = [vp, dp, dp, dp, dp, vp, vp, i32p]
     L.abn_multi_counters.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -464,6 +466,16 @@ def reduction_tree(generations, options: Options | None = None) -> int:
     if rc:
         raise AbnError(rc)
     return t.value
+
+
+def multi_plan_shard(n_windows: int, n_boot: int, n_devices: int, device_index: int):
+    """(window_offset, n_windows, boot_offset, n_boot) of one device's shard in the one-process / several-GPUs entry
+    points (abn_multi_plan_shard: host arithmetic, no device needed)."""
+    out = (C.c_int32 * 4)()
+    rc = load_library().abn_multi_plan_shard(n_windows, n_boot, n_devices, device_index, out)
+    if rc:
+        raise AbnError(rc)
+    return tuple(int(v) for v in out)
 
 
 def rccl_available() -> bool:

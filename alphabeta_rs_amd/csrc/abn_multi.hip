@@ -157,6 +157,23 @@ extern "C" int abn_multi_destroy(abn_multi* m) {
   return ABN_OK;
 }
 
+// The partition of a job over the devices, host arithmetic only (no device needed): windows in contiguous balanced
+// blocks when there are at least as many windows as devices, else every device takes all windows and a block of the
+// bootstraps.  Same rule as alphabeta_rs_amd/distributed.py::plan_shard (tests/test_distributed_cpu.py compares them).
+extern "C" int abn_multi_plan_shard(int32_t n_windows, int32_t n_boot, int32_t n_devices, int32_t device_index,
+                                    int32_t* out4) {
+  if (!out4 || n_windows <= 0 || n_boot <= 0 || n_devices <= 0 || device_index < 0 || device_index >= n_devices)
+    return ABN_ERR_INVALID_ARG;
+  int w0 = 0, wn = n_windows, b0 = 0, bn = n_boot;
+  if (n_windows < n_devices) split(n_boot, n_devices, device_index, b0, bn);
+  else split(n_windows, n_devices, device_index, w0, wn);
+  out4[0] = w0;
+  out4[1] = wn;
+  out4[2] = b0;
+  out4[3] = bn;
+  return ABN_OK;
+}
+
 extern "C" int abn_multi_create(const int32_t* devices, int32_t n_devices, const abn_options* opts,
                                 const double* generations, int32_t n_rows, int32_t n_windows, int32_t n_starts,
                                 int32_t n_boot, abn_multi** out) {
@@ -193,16 +210,9 @@ extern "C" int abn_multi_create(const int32_t* devices, int32_t n_devices, const
   m->gather = n_devices > 1 || (force && (force[0] == '1' || force[0] == '2'));
   if (force && force[0] == '2') m->uniform = false;  // ... and through the per-block broadcasts
   for (int i = 0; i < n_devices; ++i) {
-    Shard& s = m->sh[(size_t)i];
-    if (m->by_boot) {
-      s.w0 = 0;
-      s.wn = n_windows;
-      split(n_boot, n_devices, i, s.b0, s.bn);
-    } else {
-      split(n_windows, n_devices, i, s.w0, s.wn);
-      s.b0 = 0;
-      s.bn = n_boot;
-    }
+    int32_t q[4];
+    (void)abn_multi_plan_shard(n_windows, n_boot, n_devices, i, q);
+    m->sh[(size_t)i] = Shard{q[0], q[1], q[2], q[3]};
   }
   const size_t table = (size_t)n_windows * (size_t)n_boot * 7;
   for (int i = 0; i < n_devices; ++i) {

@@ -261,6 +261,10 @@ int abn_multi_run(abn_multi* m);
 int abn_multi_sync(abn_multi* m);
 /* out4 = window_offset, n_windows, boot_offset, n_boot of the shard of devices[device_index] */
 int abn_multi_shard(abn_multi* m, int32_t device_index, int32_t* out4);
+/* the same partition as host arithmetic, no device or handle needed: which windows / bootstraps device
+ * `device_index` of `n_devices` takes (contiguous balanced blocks of windows; with fewer windows than devices every
+ * device takes all windows and a block of the bootstraps) — the rule of the one-process-per-GPU path too */
+int abn_multi_plan_shard(int32_t n_windows, int32_t n_boot, int32_t n_devices, int32_t device_index, int32_t* out4);
 /* the gathered table raw[W x B x 7] in the memory of devices[device_index] (valid after abn_multi_sync) */
 int abn_multi_raw_device_ptr(abn_multi* m, int32_t device_index, void** dev_ptr);
 /* as abn_plan_download for all W windows (raw comes from the first device's gathered table); returns

@@ -136,3 +136,28 @@ def test_shard_ranges_cover_everything():
     assert (s.mode, s.window_offset, s.n_windows, s.boot_offset, s.n_boot) == ("windows", 75, 25, 0, 1000)
     s = plan_shard(1, 10000, 8, 7)
     assert (s.mode, s.n_windows, s.boot_offset, s.n_boot) == ("bootstraps", 1, 8750, 1250)
+
+
+def test_single_process_entry_shards_as_the_process_per_gpu_path(abn):
+    """abn_multi_* (one process, several GPUs) and distributed.py (one process per GPU) must cut a job the same way:
+    abn_multi_plan_shard is host arithmetic, so the C++ rule is compared with the Python one here, without a device —
+    windows in contiguous balanced blocks, bootstraps when there are fewer windows than devices, ragged remainders,
+    more devices than items."""
+    from alphabeta_rs_amd.distributed import plan_shard
+
+    for W in (1, 2, 7, 8, 9, 25, 200, 301):
+        for B in (1, 5, 1000, 10007):
+            for n in (1, 2, 3, 4, 8, 16):
+                covered_w, covered_b = [], []
+                for r in range(n):
+                    got = abn.multi_plan_shard(W, B, n, r)
+                    want = plan_shard(W, B, n, r)
+                    assert got == (want.window_offset, want.n_windows, want.boot_offset, want.n_boot), (W, B, n, r)
+                    covered_w += list(range(got[0], got[0] + got[1])) if W >= n else []
+                    covered_b += list(range(got[2], got[2] + got[3])) if W < n else []
+                assert covered_w == (list(range(W)) if W >= n else [])
+                assert covered_b == (list(range(B)) if W < n else [])
+    with pytest.raises(abn.AbnError):
+        abn.multi_plan_shard(4, 10, 2, 2)
+    with pytest.raises(abn.AbnError):
+        abn.multi_plan_shard(0, 10, 2, 0)
