@@ -213,6 +213,12 @@ constexpr long long kPersistWaves = ABN_PERSIST_WAVES;  // wavefronts of a persi
 #endif
 constexpr long long kPhaseASpecMax = ABN_PHASE_A_SPEC_MAX;  // start chains up to which phase A uses abn_fit_spec_kernel
 constexpr long long kPhaseAWideMax = 6144;  // ... and up to which it uses one wavefront per chain
+// Time slicing of persistent launches (FitArgs::quantum): evaluations a chain runs before it yields to waiting chains.
+#ifndef ABN_QUANTUM
+#define ABN_QUANTUM 256
+#endif
+constexpr int kQuantum = ABN_QUANTUM;
+constexpr size_t kSliceStateMax = (size_t)256 << 20;  // bytes of parked state (32 doubles per chain of the launch)
 constexpr int kPhaseACap = 1000;  // first-pass iteration cap of the two-pass phase A  // above this the fit kernel streams rows instead of staging them
 
 // Lanes of a wavefront per chain.  Auto: by pedigree rows, then widened until the workgroup's LDS
@@ -317,6 +323,11 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
   const bool refill = a.queue != nullptr && rmax > 0 && ng > 1 && a.iter_cap == 0 && a.resume == 0 &&
                       blocks > kPersistWaves;
   if (refill) blocks = kPersistWaves;
+  if (!refill) a.quantum = 0;
+  if (a.quantum > 0) {  // empty FIFO of parked chains: entries -1, head = tail = 0
+    HIPCHK(c, hipMemsetAsync(a.parked, 0xff, (size_t)kParkShards * a.park_cap * sizeof(int), st));
+    HIPCHK(c, hipMemsetAsync(a.park_ht, 0, (size_t)kParkShards * kParkHeaderInts * sizeof(unsigned), st));
+  }
   dim3 grid((unsigned)blocks);
   hipError_t e;
   switch (lanes) {
@@ -786,6 +797,8 @@ struct abn_plan {
   // per phase (A, B): [2*ph] evaluations not executed (fixed-point skip), [2*ph+1] chain queue of the persistent kernel
   DevBuf<unsigned long long> skipped;
   bool twopass_a = false;
+  DevBuf<int> slice_buf;      // time slicing: head, tail, then the FIFO of parked chains
+  unsigned slice_cap = 0;
   bool stream_b = false;
   double* raw = nullptr;  // raw_own.p or caller-bound
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -891,6 +904,15 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   if (p->twopass_a) {
     PALLOC(nm_state, W * S * 32);
     PALLOC(susp_list, W * S + 1);
+  }
+  {  // time slicing for launches that outgrow the resident set of the persistent kernel (4 x kPersistWaves chains at 16 lanes)
+    const size_t chains = W * std::max(S, B);
+    if (kQuantum > 0 && p->lanes < kWave && chains > (size_t)kPersistWaves * (size_t)(kWave / p->lanes) &&
+        chains * 32 * sizeof(double) <= kSliceStateMax && chains < (1u << 27) && p->opt.window_groups <= 1) {
+      if (p->nm_state.n < chains * 32) PALLOC(nm_state, chains * 32);
+      p->slice_cap = (unsigned)(chains * 16 / kParkShards + 4096);   // per shard; a full shard just stops parking
+      PALLOC(slice_buf, (size_t)kParkShards * ((size_t)kParkHeaderInts + (size_t)p->slice_cap));
+    }
   }
   p->stream_b = n_boot > 0 && fit_streams(n_rows, p->topo.chain_stride, p->lanes) && p->opt.stream_mode == 0;
   if (p->stream_b) PALLOC(dstar, W * B * N);
@@ -1022,6 +1044,13 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   a.raw = nullptr;
   a.skipped = p->skipped.p;
   a.queue = refill ? reinterpret_cast<unsigned*>(p->skipped.p + 1) : nullptr;
+  if (refill && p->slice_cap > 0 && w0 == 0 && wn == p->W) {
+    a.quantum = kQuantum;
+    a.park_cap = p->slice_cap;
+    a.park_ht = reinterpret_cast<unsigned*>(p->slice_buf.p);
+    a.parked = p->slice_buf.p + kParkShards * kParkHeaderInts;
+    a.state = p->nm_state.p;
+  }
   if (timed) HIPCHK(c, hipEventRecord(p->ev[0], st));
   // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once,
   // a fourth keeps the simplex and prepares the next candidates meanwhile (abn_fit_spec_kernel)
@@ -1103,6 +1132,13 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   a.raw = p->raw + o * B * 7;
   a.skipped = p->skipped.p + 2;
   a.queue = refill ? reinterpret_cast<unsigned*>(p->skipped.p + 3) : nullptr;
+  if (refill && p->slice_cap > 0 && w0 == 0 && wn == p->W) {
+    a.quantum = kQuantum;
+    a.park_cap = p->slice_cap;
+    a.park_ht = reinterpret_cast<unsigned*>(p->slice_buf.p);
+    a.parked = p->slice_buf.p + kParkShards * kParkHeaderInts;
+    a.state = p->nm_state.p;
+  }
   if (timed) HIPCHK(c, hipEventRecord(p->ev[4], st));
   if (p->stream_b) {  // gather the bootstrap observations once per fit, then stream them
     double* dst = p->dstar.p + o * B * N;

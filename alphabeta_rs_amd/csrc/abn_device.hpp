@@ -51,6 +51,8 @@ constexpr int ST_EXPAND = 6;    // evaluating the expanded point
 constexpr int ST_CONTRACT = 7;  // evaluating the contracted point
 constexpr int ST_SHRINK1 = 8;   // 8..11: evaluating shrunk vertex k = st-7
 constexpr int ST_DONE = 12;
+constexpr int kParkHead = 0, kParkTail = 64, kParkAvail = 128, kParkHeaderInts = 192;  // one cache line each
+constexpr int kParkShards = 64;  // independent FIFOs (workgroup b uses b mod 64): a cache line serves ~100 M atomics/s
 constexpr int kFitSuspended = 4;  // internal status between the two passes of a long chain
 
 struct FitInfoDev {  // layout of abn_fit_info (include/abneutral.h)
@@ -118,6 +120,19 @@ struct FitArgs {
   int no_skip;
   unsigned long long* skipped;
   unsigned* queue;       // abn_fit_refill_kernel: next chain to start (zeroed by the host); nullptr = no persistent launch
+  // Time slicing in the persistent kernel (quantum > 0).  A chain that has run `quantum` evaluations while others wait
+  // (unstarted chains in the queue, or parked ones) stores its state (`state`, 32 doubles, as the two-pass hand-over)
+  // at its next iteration boundary and appends itself to the FIFO `parked`; its group takes the next waiting chain —
+  // a fresh one while there are any, else the oldest parked one.  Chains of very different length then advance
+  // together and the launch no longer ends with a few long chains on an idle GPU.  Same arithmetic, same bits.
+  //   park_ht[kParkHead] = next entry to take, [kParkTail] = entries reserved, [kParkAvail] = entries published and
+  //   not yet claimed (a signed credit: a group claims one with an atomic subtract and gives it back if there was
+  //   none — no compare-and-swap loop: thousands of groups reach the end of a quantum together); parked[] starts at
+  //   -1 and an entry is published by its (agent-scope) store after the chain's state has been written through.
+  int quantum;
+  unsigned park_cap;     // entries of parked[] PER SHARD (kParkShards shards, each with its own three counters)
+  unsigned* park_ht;
+  int* parked;
   double sd_tol;
   double gap_tol;        // 64 * sd_tol, precomputed on the host so that it stays a scalar (kernarg) operand
   // outputs (fit order)
@@ -1031,6 +1046,15 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
 // Every chain computes exactly what it computes in abn_fit_kernel (same code for the evaluation, the same
 // Nelder-Mead update), and results are written by chain index: outputs are bit-identical and independent
 // of the schedule.  Resident mode only (RMAX > 0), single pass.
+// Time slicing (FitArgs::quantum > 0): the queue alone leaves a long tail — the launch ends with whole long chains
+// that started late, on a GPU that is emptying.  So a chain that has run a quantum of evaluations while others wait
+// parks itself at its next iteration boundary (state to memory, an entry in its workgroup's FIFO shard) and its group
+// takes the next waiting chain: chains of different length advance together and the groups stay busy to the end
+// (C4 shard phase B 4.96 -> 4.44 ms at a quantum of 256; 128 costs more in parks than it gains, 768 gains less).
+// What the protocol needs on this hardware (each learnt from a measurement): no agent-scope fence per
+// park (it writes back and invalidates the XCD's L2: state through sc1 stores / loads and a wavefront-level wait); no
+// compare-and-swap loop (thousands of groups end a quantum together: a credit counter instead); the counters sharded
+// over 64 sets of cache lines (one line serves ~100 M device-scope atomics a second).
 // ------------------------------------------------------------------------------------------------
 constexpr int ST_IDLE = 13;
 
@@ -1055,6 +1079,9 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
   uint32_t* tri_s = reinterpret_cast<uint32_t*>(dobs + ((N + 1) & ~1));  // this group's copy of the triple list
 
   // ---- per-group constants of the topology: triple list in LDS, this lane's row -> triple ids in registers
+  // time slicing: this workgroup's FIFO of parked chains (shards are statistically alike: no stealing)
+  unsigned* const pht = a.quantum > 0 ? a.park_ht + (blockIdx.x & (kParkShards - 1)) * kParkHeaderInts : nullptr;
+  int* const pk = a.quantum > 0 ? a.parked + (size_t)(blockIdx.x & (kParkShards - 1)) * a.park_cap : nullptr;
   const bool canon = a.tree == kTreeCanon;  // the canonical 64-accumulator tree (FitArgs::tree), else G accumulators
   uint32_t tidp[(RR + 1) / 2];
   for (int t = gl; t < K; t += G) tri_s[t] = a.tri[t];
@@ -1075,6 +1102,8 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
   double fr = 0.0, best_cost = __builtin_inf();
   bool have_best = false;
   int fin_status = 2;
+  int q_start = 0;           // time slicing: evals of this chain when its current quantum began
+  bool fresh_done = false;   // this group has seen the queue of unstarted chains empty
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     vx[k] = 0.0;
@@ -1127,7 +1156,57 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
     have_best = false;
     fin_status = 2;
     fr = 0.0;
+    // first quantum shortened by a per-chain amount: the chains that start together do not all park together
+    q_start = a.quantum > 0 ? -(int)((chain * 2654435761u >> 16) % (unsigned)a.quantum) : 0;
     st = ST_INIT0;
+  };
+  // take a parked chain up again: observations to LDS as for a fresh chain, simplex / costs / best / counters as
+  // stored at the iteration boundary (the caller has fenced: the state is the parking group's), centroid and
+  // reflection recomputed with the same arithmetic
+  auto resume_chain = [&]() {
+    const int w = (int)(chain / (unsigned)a.C);
+    const int wi = w * a.wstride;
+    const size_t wN = (size_t)w * (size_t)N;
+    if (gl == 0) {
+      const double p_uu0 = a.p_uu[wi];
+      wconst[0] = p_uu0;
+      wconst[1] = 1.0 - p_uu0;
+      wconst[2] = a.eqp[wi];
+      wconst[3] = a.eqp_w[wi] * (double)N;
+    }
+    const uint32_t* idx_row = (a.dmode == 1) ? a.idx + (size_t)chain * (size_t)N : nullptr;
+    const size_t dN = (a.dmode == 2) ? (size_t)chain * (size_t)N : wN;
+#pragma unroll
+    for (int q = 0; q < RR; ++q) {
+      const int i = gl + G * q;
+      if (i < N)
+        dobs[i] = (a.dmode == 1) ? a.pred[wN + i] + a.resid[wN + idx_row[i]] : a.D[dN + i];
+    }
+    // agent-scope loads (past the caches, as the parking group's stores): no cache invalidation needed
+    double* sp = a.state + (size_t)chain * 32;
+    auto ld = [&](int i) { return __hip_atomic_load(sp + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      vx[k] = ld(4 * k + dim);
+      c[k] = ld(20 + k);
+    }
+    bx = ld(25 + dim);
+    best_cost = ld(29);
+    const long long ie = __double_as_longlong(ld(30));
+    iter = (int)(ie & 0xffffffffll);
+    evals = (int)(ie >> 32);
+    have_best = __double_as_longlong(ld(31)) != 0;
+    fin_status = 2;
+    fr = 0.0;
+    double acc = vx[0];
+    acc = acc + vx[1];
+    acc = acc + vx[2];
+    acc = acc + vx[3];
+    x0 = acc * (1.0 / 4.0);
+    xr = x0 + (x0 - vx[4]) * 1.0;
+    xc = xr;
+    q_start = evals;
+    st = ST_REFLECT;
   };
   if (chain < total) setup_chain();
   __syncthreads();
@@ -1213,8 +1292,19 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
     if (converged) status = 0;
     else if (iter >= a.max_iters) status = 1;
     else if (best_cost <= -__builtin_inf()) status = 3;
-    const bool done = status >= 0;
-    fin_status = done ? (have_best ? status : 2) : fin_status;
+    // time slicing: the quantum is used up and somebody is waiting (an unstarted or a parked chain) -> park.
+    // The counters are read once per quantum; a stale answer costs at most a park that is taken up again at once.
+    bool suspend = false;
+    if (a.quantum > 0 && status < 0 && evals - q_start >= a.quantum) {
+      const unsigned fq = __hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int av = __hip_atomic_load(reinterpret_cast<int*>(pht) + kParkAvail, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned tl = __hip_atomic_load(pht + kParkTail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      suspend = (gridDim.x * NG + fq < total || av > 0) && tl + gridDim.x * NG / kParkShards + NG < a.park_cap;
+      q_start = evals;
+    }
+    const bool done = status >= 0 || suspend;
+    fin_status = (status >= 0) ? (have_best ? status : 2) : (suspend ? kFitSuspended : fin_status);
     double acc = vx[0];
     acc = acc + vx[1];
     acc = acc + vx[2];
@@ -1305,7 +1395,23 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
       const bool fin = st == ST_DONE;
       const double b0 = dpp_mov<kDppQuadBcast0>(bx), b1 = dpp_mov<kDppQuadBcast1>(bx);
       unsigned nxt = 0xffffffffu;
-      if (fin) {
+      const bool parking = fin && fin_status == kFitSuspended;
+      if (parking) {  // time slicing: the chain's state (32 doubles), stored past the caches (agent scope): the group
+        double* sp = a.state + (size_t)chain * 32;  // that takes the chain up again may sit on another XCD
+        auto sd = [&](int i, double v) { __hip_atomic_store(sp + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        if (gl < 4) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) sd(4 * k + gl, vx[k]);
+          sd(25 + gl, bx);
+        }
+        if (gl == 0) {
+#pragma unroll
+          for (int k = 0; k < 5; ++k) sd(20 + k, c[k]);
+          sd(29, best_cost);
+          sd(30, __longlong_as_double((long long)(unsigned)iter | ((long long)evals << 32)));
+          sd(31, __longlong_as_double(have_best ? 1ll : 0ll));
+        }
+      } else if (fin) {
         if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
         if (gl == 0) {
           FitInfoDev fo;
@@ -1315,7 +1421,6 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
           fo.status = fin_status;
           fo.lanes = a.tree;  // reduction-tree code (oracle: `lanes`)
           a.info[chain] = fo;
-          nxt = gridDim.x * NG + atomicAdd(a.queue, 1u);
         }
         if (a.raw) {
           double* ro = a.raw + (size_t)chain * 7;
@@ -1325,12 +1430,53 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
           if (gl == 6) ro[6] = p_uu_est(b0, b1);
         }
       }
+      if (a.quantum > 0) {
+        // publish the parked chains of this wavefront: the state stores (written through to memory) have completed
+        // before the entry is stored — a wavefront-level wait, NOT an agent-scope fence: that would write back and
+        // invalidate the XCD's whole L2 at every park (measured: a 5 ms launch took 2 s).  All of this wavefront's
+        // entries are out before any of its groups looks for one (no group can wait for an entry of its own wavefront).
+        if (__ballot(parking) != 0ull) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (parking && gl == 0) {
+          const unsigned pos = atomicAdd(pht + kParkTail, 1u);
+          __hip_atomic_store(pk + pos, (int)chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicAdd(reinterpret_cast<int*>(pht) + kParkAvail, 1);
+        }
+      }
+      bool take_parked = false;
+      if (fin && gl == 0) {
+        if (!fresh_done) {
+          const unsigned f = gridDim.x * NG + atomicAdd(a.queue, 1u);
+          if (f < total) nxt = f;
+          else fresh_done = true;
+        }
+        if (nxt == 0xffffffffu && a.quantum > 0) {
+          // oldest parked chain, if any: claim a credit first (given back if there was none), then a ticket — a
+          // ticket is only ever taken against a published entry, so none is lost and nobody loops
+          int* avail = reinterpret_cast<int*>(pht) + kParkAvail;
+          if (atomicSub(avail, 1) > 0) {
+            const unsigned h = atomicAdd(pht + kParkHead, 1u);
+            int cpk;  // entries are published in any order: the one of this ticket may be a few instructions away
+            unsigned spins = 0;  // (its writer is a running wavefront past its reservation; bounded all the same: a
+            while ((cpk = __hip_atomic_load(pk + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {  // lost entry
+              __builtin_amdgcn_s_sleep(1);                                                                // must fail
+              if (++spins > (1u << 24)) __builtin_trap();                                                 // loudly, not hang)
+            }
+            nxt = (unsigned)cpk;
+            take_parked = true;
+          } else {
+            atomicAdd(avail, 1);
+          }
+        }
+      }
       nxt = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (g * G), (int)nxt);  // the group leader's draw
+      take_parked = __builtin_amdgcn_ds_bpermute(4 * (g * G), (int)take_parked) != 0;
+      fresh_done = __builtin_amdgcn_ds_bpermute(4 * (g * G), (int)fresh_done) != 0;
       if (fin) {
         st = ST_IDLE;
         if (nxt < total) {
           chain = nxt;
-          setup_chain();
+          if (take_parked) resume_chain();
+          else setup_chain();
         }
       }
       __syncthreads();
