@@ -219,7 +219,7 @@ constexpr long long kPhaseAWideMax = 6144;  // ... and up to which it uses one w
 #endif
 constexpr int kQuantum = ABN_QUANTUM;
 constexpr size_t kSliceStateMax = (size_t)256 << 20;  // bytes of parked state (32 doubles per chain of the launch)
-constexpr int kPhaseACap = 1000;  // first-pass iteration cap of the two-pass phase A  // above this the fit kernel streams rows instead of staging them
+constexpr int kPhaseACap = 1000;  // first-pass iteration cap of the two-pass phase A
 
 // Lanes of a wavefront per chain.  Auto: by pedigree rows, then widened until the workgroup's LDS
 // (64/G chains x chain_stride doubles) leaves room for >= 8 workgroups per CU (160 KiB LDS).
@@ -1401,7 +1401,7 @@ extern "C" int abn_plan_device_bytes(abn_plan* p, int64_t* bytes) {
   t += p->D.bytes() + p->pred.bytes() + p->resid.bytes() + p->p_uu.bytes() + p->eqp.bytes() + p->eqp_w.bytes();
   t += p->simplexA.bytes() + p->bestA.bytes() + p->model.bytes() + p->lse.bytes() + p->bestB.bytes();
   t += p->raw_own.bytes() + p->infoA.bytes() + p->infoB.bytes() + p->best_start.bytes() + p->idx.bytes();
-  t += p->dstar.bytes() + p->nm_state.bytes() + p->susp_list.bytes() + p->skipped.bytes();
+  t += p->dstar.bytes() + p->nm_state.bytes() + p->susp_list.bytes() + p->skipped.bytes() + p->slice_buf.bytes();
   t += p->dtopo.tri.bytes() + p->dtopo.tid.bytes();
   *bytes = (int64_t)t;
   return ABN_OK;
