@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <unordered_map>
@@ -30,6 +31,7 @@ constexpr size_t kPoolBufMax = (size_t)64 << 20, kPoolTotalMax = (size_t)256 << 
 struct BufPool {
   std::vector<std::pair<void*, size_t>> free_list;
   size_t held = 0;
+  bool closed = false;  // abn_shutdown has run: buffers of plans that outlive their context are freed, not pooled
   void* take(size_t bytes, size_t* cap) {
     size_t best = free_list.size();
     for (size_t i = 0; i < free_list.size(); ++i)
@@ -45,7 +47,7 @@ struct BufPool {
     return p;
   }
   bool give(void* p, size_t cap) {
-    if (cap > kPoolBufMax || held + cap > kPoolTotalMax) return false;
+    if (closed || cap > kPoolBufMax || held + cap > kPoolTotalMax) return false;
     free_list.emplace_back(p, cap);
     held += cap;
     return true;
@@ -62,15 +64,17 @@ struct abn_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::vector<hipStream_t> side;  // lazily created: window groups of a plan run concurrently on these
-  BufPool pool;
+  // shared with every DevBuf drawn from it: a plan destroyed after abn_shutdown (easy from Python: ctx.close() before
+  // the Plan is collected) still finds its pool — closed, so its buffers are simply freed
+  std::shared_ptr<BufPool> pool = std::make_shared<BufPool>();
   std::string err;
 };
 
 // the pool DevBuf allocations of the current call draw from (set by PoolScope around the entry points)
-static thread_local BufPool* g_pool = nullptr;
+static thread_local std::shared_ptr<BufPool> g_pool;
 struct PoolScope {
-  BufPool* prev;
-  explicit PoolScope(abn_ctx* c) : prev(g_pool) { g_pool = c ? &c->pool : nullptr; }
+  std::shared_ptr<BufPool> prev;
+  explicit PoolScope(abn_ctx* c) : prev(g_pool) { g_pool = c ? c->pool : nullptr; }
   ~PoolScope() { g_pool = prev; }
 };
 
@@ -91,7 +95,7 @@ struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
   size_t cap = 0;          // bytes of the allocation behind p
-  BufPool* pool = nullptr;  // where it came from / goes back to
+  std::shared_ptr<BufPool> pool;  // where it came from / goes back to
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
@@ -115,6 +119,11 @@ struct DevBuf {
       }
     }
     hipError_t e = hipMalloc((void**)&p, bytes);
+    if (e == hipErrorOutOfMemory && pool && pool->held) {  // the pool may be holding what this allocation needs
+      (void)hipGetLastError();
+      pool->clear();
+      e = hipMalloc((void**)&p, bytes);
+    }
     if (e == hipSuccess) {
       n = count;
       cap = bytes;
@@ -240,7 +249,8 @@ static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree);
 // LDS-resident: the canonical 64-accumulator tree, which every kernel — packed, one wavefront per chain, four
 // wavefronts per chain — runs at its native cost.  Streamed pedigrees and explicit lane counts: one accumulator per
 // lane of the packed kernel.
-static int pick_tree(int n, int requested, int chain_stride, int lanes) {
+static int pick_tree(int n, int requested, int chain_stride, int lanes, int strict = 0) {
+  if (strict) return 1;  // serial row order (abn_options.strict_order): no tree
   if (requested != 0 || fit_streams(n, chain_stride, lanes)) return lanes;
   return kTreeCanon;
 }
@@ -256,23 +266,28 @@ static int pick_rmax(int n, int lanes) {
   return 0;  // stream mode
 }
 
-template <int G, bool TP>
+template <int G, bool TP, bool STRICT>
 static hipError_t launch_fit_gt(const FitArgs& a, int rmax, dim3 grid, size_t lds, hipStream_t s) {
   switch (rmax) {
-    case 1: hipLaunchKernelGGL((abn_fit_kernel<G, 1, TP>), grid, dim3(kWave), lds, s, a); break;
-    case 2: hipLaunchKernelGGL((abn_fit_kernel<G, 2, TP>), grid, dim3(kWave), lds, s, a); break;
-    case 4: hipLaunchKernelGGL((abn_fit_kernel<G, 4, TP>), grid, dim3(kWave), lds, s, a); break;
-    case 8: hipLaunchKernelGGL((abn_fit_kernel<G, 8, TP>), grid, dim3(kWave), lds, s, a); break;
+    case 1: hipLaunchKernelGGL((abn_fit_kernel<G, 1, TP, STRICT>), grid, dim3(kWave), lds, s, a); break;
+    case 2: hipLaunchKernelGGL((abn_fit_kernel<G, 2, TP, STRICT>), grid, dim3(kWave), lds, s, a); break;
+    case 4: hipLaunchKernelGGL((abn_fit_kernel<G, 4, TP, STRICT>), grid, dim3(kWave), lds, s, a); break;
+    case 8: hipLaunchKernelGGL((abn_fit_kernel<G, 8, TP, STRICT>), grid, dim3(kWave), lds, s, a); break;
     case 16:  // one wavefront per chain only (pick_rmax)
-      hipLaunchKernelGGL((abn_fit_kernel<64, 16, TP>), grid, dim3(kWave), lds, s, a);
+      hipLaunchKernelGGL((abn_fit_kernel<64, 16, TP, STRICT>), grid, dim3(kWave), lds, s, a);
       break;
     case -1:
-      if (hipError_t e = allow_lds(reinterpret_cast<const void*>(&abn_fit_kernel<G, -1, TP>), lds)) return e;
-      hipLaunchKernelGGL((abn_fit_kernel<G, -1, TP>), grid, dim3(kWave), lds, s, a);
+      if (STRICT) {  // strict order has one stream variant (chunks of 8 G rows)
+        if (hipError_t e = allow_lds(reinterpret_cast<const void*>(&abn_fit_kernel<G, 0, TP, STRICT>), lds)) return e;
+        hipLaunchKernelGGL((abn_fit_kernel<G, 0, TP, STRICT>), grid, dim3(kWave), lds, s, a);
+        break;
+      }
+      if (hipError_t e = allow_lds(reinterpret_cast<const void*>(&abn_fit_kernel<G, -1, TP, false>), lds)) return e;
+      hipLaunchKernelGGL((abn_fit_kernel<G, -1, TP, false>), grid, dim3(kWave), lds, s, a);
       break;
     default:
-      if (hipError_t e = allow_lds(reinterpret_cast<const void*>(&abn_fit_kernel<G, 0, TP>), lds)) return e;
-      hipLaunchKernelGGL((abn_fit_kernel<G, 0, TP>), grid, dim3(kWave), lds, s, a);
+      if (hipError_t e = allow_lds(reinterpret_cast<const void*>(&abn_fit_kernel<G, 0, TP, STRICT>), lds)) return e;
+      hipLaunchKernelGGL((abn_fit_kernel<G, 0, TP, STRICT>), grid, dim3(kWave), lds, s, a);
       break;
   }
   return hipGetLastError();
@@ -291,25 +306,37 @@ template <int G>
 static hipError_t launch_fit_g(const FitArgs& a, int rmax, dim3 grid, size_t lds, hipStream_t s, bool refill) {
   const bool twopass = a.iter_cap > 0 || a.resume != 0;
   if (refill) return launch_fit_refill<G>(a, rmax, grid, lds, s);
-  return twopass ? launch_fit_gt<G, true>(a, rmax, grid, lds, s) : launch_fit_gt<G, false>(a, rmax, grid, lds, s);
+  if (a.strict) return launch_fit_gt<G, false, true>(a, rmax, grid, lds, s);  // launch_fit: never two-pass, never persistent
+  return twopass ? launch_fit_gt<G, true, false>(a, rmax, grid, lds, s) : launch_fit_gt<G, false, false>(a, rmax, grid, lds, s);
 }
 
 // `a.chain_stride` must be the topology's scratch stride (kPw*TP + KP + 4, even); the resident variant adds an even
 // number of doubles (observations + triple list): every chain's region stays 16-byte aligned for load_matrix.
-static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
+// persistent (nullable): set to true when the launch ran abn_fit_refill_kernel (a.slice_status then counts its fits)
+static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, bool* persistent = nullptr) {
+  if (persistent) *persistent = false;
   const long long chains = (long long)a.W * a.C;
   if (chains <= 0) return ABN_OK;
   const int ng = kWave / lanes;
   int rmax = pick_rmax(a.N, lanes);
-  // the reduction tree: the canonical one (any resident kernel) or one accumulator per lane
-  if (a.tree != kTreeCanon) a.tree = lanes;
-  const int np = ((a.N + 1) & ~1) + (((a.K + 1) / 2 + 1) & ~1);  // resident observations + this chain's triple list (even: 16-byte aligned chains)
+  // the reduction tree: the canonical one (any resident kernel) or one accumulator per lane; strict order: none (serial)
+  if (a.strict) {
+    if (a.iter_cap > 0 || a.resume != 0)
+      return set_err(c, ABN_ERR_INVALID_ARG, "internal: strict order has no two-pass variant");
+    a.tree = 1;
+    a.queue = nullptr;  // no persistent variant either
+  } else if (a.tree != kTreeCanon) {
+    a.tree = lanes;
+  }
+  // resident observations + this chain's triple list (even: 16-byte aligned chains) (+ strict order: the rows' terms)
+  const int np = ((a.N + 1) & ~1) + (((a.K + 1) / 2 + 1) & ~1) + (a.strict ? ((a.N + 1) & ~1) : 0);
   if (rmax > 0) {
     if ((size_t)ng * (size_t)(a.chain_stride + np) * sizeof(double) > kLdsResidentMax) rmax = 0;
     else a.chain_stride += np;
   }
   if (rmax <= 0 && a.tree == kTreeCanon)
     return set_err(c, ABN_ERR_INVALID_ARG, "internal: the canonical tree needs an LDS-resident pedigree");
+  if (rmax <= 0 && a.strict) a.chain_stride += kStrictRowsPerLane * lanes;  // one chunk of terms
   // stream mode: rows shorter than one trip of the deep loop (kStreamBlocks x 4 rows x lanes) use the pair-loop variant
   if (rmax == 0 && a.N < 2 * kStreamBlocks * kStreamVec * lanes) rmax = -1;
   const size_t lds = (size_t)ng * (size_t)a.chain_stride * sizeof(double);
@@ -324,6 +351,8 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st) {
                       blocks > kPersistWaves;
   if (refill) blocks = kPersistWaves;
   if (!refill) a.quantum = 0;
+  if (refill && a.slice_status) HIPCHK(c, hipMemsetAsync(a.slice_status, 0, 2 * sizeof(unsigned), st));
+  if (persistent) *persistent = refill;
   if (a.quantum > 0) {  // empty FIFO of parked chains: entries -1, head = tail = 0
     HIPCHK(c, hipMemsetAsync(a.parked, 0xff, (size_t)kParkShards * a.park_cap * sizeof(int), st));
     HIPCHK(c, hipMemsetAsync(a.park_ht, 0, (size_t)kParkShards * kParkHeaderInts * sizeof(unsigned), st));
@@ -359,10 +388,10 @@ static long long spec_max_chains(int n_rows) {
 
 // a wavefront per chain runs the canonical tree whenever the pedigree is LDS-resident at 64 lanes per chain
 static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree) {
-  if (tree != kTreeCanon) return tree == kWave;
+  if (tree != kTreeCanon && tree != 1) return tree == kWave;
   const int rmax = pick_rmax(n_rows, kWave);
   if (rmax <= 0) return false;
-  const int np = ((n_rows + 1) & ~1) + n_rows / 2 + 2;
+  const int np = ((n_rows + 1) & ~1) + n_rows / 2 + 2 + (tree == 1 ? ((n_rows + 1) & ~1) : 0);  // strict order: + the terms
   return (size_t)(chain_stride + np) * sizeof(double) <= kLdsResidentMax;
 }
 
@@ -444,8 +473,9 @@ extern "C" int abn_reduction_tree(const abn_options* opts, const double* generat
   const int rc = build_topology(generations, n_rows, 3, t);
   if (rc) return rc;
   const int lanes = pick_lanes(n_rows, o.lanes_per_chain, t.chain_stride);
-  *tree = fit_streams(n_rows, t.chain_stride, lanes) ? (lanes | ((kStreamVec - 1) << 8))
-                                                     : pick_tree(n_rows, o.lanes_per_chain, t.chain_stride, lanes);
+  *tree = o.strict_order ? 1
+          : fit_streams(n_rows, t.chain_stride, lanes) ? (lanes | ((kStreamVec - 1) << 8))
+                                                       : pick_tree(n_rows, o.lanes_per_chain, t.chain_stride, lanes);
   return ABN_OK;
 }
 
@@ -494,7 +524,8 @@ extern "C" int abn_shutdown(abn_ctx* c) {
   if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
   for (auto st : c->side) (void)hipStreamDestroy(st);
   (void)hipSetDevice(c->device);
-  c->pool.clear();
+  c->pool->clear();
+  c->pool->closed = true;
   delete c;
   return ABN_OK;
 }
@@ -762,7 +793,8 @@ extern "C" int abn_fit_batch(abn_ctx* c, const abn_options* opts, const double* 
   a.info = dinfo.p;
   a.raw = nullptr;
   const int lanes = pick_lanes(N, o.lanes_per_chain, t.chain_stride);
-  a.tree = pick_tree(N, o.lanes_per_chain, t.chain_stride, lanes);
+  a.strict = o.strict_order ? 1 : 0;
+  a.tree = pick_tree(N, o.lanes_per_chain, t.chain_stride, lanes, a.strict);
   rc = launch_fit(c, a, lanes, c->stream);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(best, dbest.p, dbest.bytes(), hipMemcpyDeviceToHost, c->stream));
@@ -799,6 +831,8 @@ struct abn_plan {
   bool twopass_a = false;
   DevBuf<int> slice_buf;      // time slicing: head, tail, then the FIFO of parked chains
   unsigned slice_cap = 0;
+  DevBuf<unsigned> slice_status;   // per phase: error word, fits finished by the persistent kernel (FitArgs::slice_status)
+  long long persist_expected[2] = {0, 0};  // chains the last persistent launch of phase A / B had to finish (0: none)
   bool stream_b = false;
   double* raw = nullptr;  // raw_own.p or caller-bound
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -847,7 +881,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
     return set_err(c, rc, abn_status_string(rc));
   }
   p->lanes = pick_lanes(n_rows, p->opt.lanes_per_chain, p->topo.chain_stride);
-  p->tree = pick_tree(n_rows, p->opt.lanes_per_chain, p->topo.chain_stride, p->lanes);
+  p->tree = pick_tree(n_rows, p->opt.lanes_per_chain, p->topo.chain_stride, p->lanes, p->opt.strict_order);
   p->lanes_a = p->lanes;
   // Phase A is latency-bound while its chains fit the machine about twice over (3 wavefronts x 1024 SIMDs): one
   // wavefront per chain then beats packing several chains into a wavefront, and below ~1000 chains the
@@ -894,13 +928,14 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   PALLOC(infoB, W * B);
   PALLOC(raw_own, W * B * 7);
   PALLOC(skipped, 4);
+  PALLOC(slice_status, 4);
   // Phase A with many chains when the repetitions of stuck fits must be executed (no_fixed_point_skip): 7 % of
   // random starts run into argmin's fixed point and repeat it up to iteration 10000; dispatched late in one launch
   // such a chain runs alone for tens of milliseconds.  Two passes: every chain for at most kPhaseACap iterations,
   // then the unfinished ones, compacted, all resident at once.  With the default skip those chains end at once and
   // one pass is faster (metaprofile shape, 30000 start chains: 14.6 ms against 18.3 ms).
   p->twopass_a = (long long)n_windows * n_starts > 4096 && p->opt.max_iters_start > kPhaseACap &&
-                 p->opt.no_fixed_point_skip != 0 && p->opt.shrink_on_failed_contraction == 0;
+                 p->opt.no_fixed_point_skip != 0 && p->opt.shrink_on_failed_contraction == 0 && !p->opt.strict_order;
   if (p->twopass_a) {
     PALLOC(nm_state, W * S * 32);
     PALLOC(susp_list, W * S + 1);
@@ -1013,6 +1048,7 @@ static void fill_common(const abn_plan* p, FitArgs& a) {
   a.boot_offset = p->boot_offset;
   a.wid = p->wid.p;
   a.tree = p->tree;
+  a.strict = p->opt.strict_order ? 1 : 0;
   a.W = p->W;
   a.shrink_variant = p->opt.shrink_on_failed_contraction ? 1 : 0;
   a.no_skip = p->opt.no_fixed_point_skip ? 1 : 0;
@@ -1051,11 +1087,14 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
     a.parked = p->slice_buf.p + kParkShards * kParkHeaderInts;
     a.state = p->nm_state.p;
   }
+  const bool whole = w0 == 0 && wn == p->W;   // window groups on side streams share the plan's status words: unchecked
+  if (whole) a.slice_status = p->slice_status.p;
+  bool persistent = false;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[0], st));
   // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once,
   // a fourth keeps the simplex and prepares the next candidates meanwhile (abn_fit_spec_kernel)
-  const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && (long long)p->W * p->S <= spec_max_chains(p->N) &&
-                    spec_applicable(a);
+  const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && !a.strict &&
+                    (long long)p->W * p->S <= spec_max_chains(p->N) && spec_applicable(a);
   int rc;
   if (spec) {
     rc = launch_fit_spec(c, a, st);
@@ -1074,9 +1113,10 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
       rc = launch_fit(c, a, p->lanes_a, st);        // pass 2: the parked chains, to the end
     }
   } else {
-    rc = launch_fit(c, a, p->lanes_a, st);
+    rc = launch_fit(c, a, p->lanes_a, st, &persistent);
   }
   if (rc) return rc;
+  if (whole) p->persist_expected[0] = persistent ? (long long)wn * p->S : 0;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[1], st));
   SelectArgs s{};
   s.tri = a.tri;
@@ -1139,6 +1179,9 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
     a.parked = p->slice_buf.p + kParkShards * kParkHeaderInts;
     a.state = p->nm_state.p;
   }
+  const bool whole = w0 == 0 && wn == p->W;
+  if (whole) a.slice_status = p->slice_status.p + 2;
+  bool persistent = false;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[4], st));
   if (p->stream_b) {  // gather the bootstrap observations once per fit, then stream them
     double* dst = p->dstar.p + o * B * N;
@@ -1151,8 +1194,8 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
     a.D = dst;
   }
   // few bootstraps: latency-bound like phase A -> the speculative kernel (four wavefronts per chain)
-  bool spec = a.dmode == 1 && p->opt.lanes_per_chain == 0 && (long long)p->W * p->B <= spec_max_chains(p->N) &&
-              spec_applicable(a);
+  bool spec = a.dmode == 1 && p->opt.lanes_per_chain == 0 && !a.strict &&
+              (long long)p->W * p->B <= spec_max_chains(p->N) && spec_applicable(a);
   int lanes_b = p->lanes;
   // ... and up to 192 chains per packed lane (3072 for the 16-lane kernels) a wavefront per chain still beats packing
   // several chains into one (scripts/b_kernel_sweep.py, C3 topology: 2000 bootstraps 1.36 ms against 1.74 ms packed and
@@ -1163,13 +1206,14 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
 #ifdef ABN_MEASUREMENT_KNOBS  // ABN_PHASE_B_KERNEL = spec | wide | packed
   if (const char* e = getenv("ABN_PHASE_B_KERNEL")) {
     const bool can_wide = a.dmode == 1 && p->opt.lanes_per_chain == 0 && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree);
-    if (!strcmp(e, "spec")) spec = can_wide && spec_applicable(a);
+    if (!strcmp(e, "spec")) spec = can_wide && !a.strict && spec_applicable(a);
     if (!strcmp(e, "wide")) { spec = false; if (can_wide) lanes_b = kWave; }
     if (!strcmp(e, "packed")) spec = false;
   }
 #endif
-  int rc = spec ? launch_fit_spec(c, a, st) : launch_fit(c, a, lanes_b, st);
+  int rc = spec ? launch_fit_spec(c, a, st) : launch_fit(c, a, lanes_b, st, &persistent);
   if (rc) return rc;
+  if (whole) p->persist_expected[1] = persistent ? (long long)wn * p->B : 0;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[5], st));
   return ABN_OK;
 }
@@ -1314,7 +1358,19 @@ extern "C" int abn_plan_download(abn_plan* p, double* models, double* pred, doub
     bs.resize(W);
     HIPCHK(c, hipMemcpyAsync(bs.data(), p->best_start.p, p->best_start.bytes(), hipMemcpyDeviceToHost, s));
   }
+  unsigned sl[4] = {0, 0, 0, 0};
+  const bool check_persist = p->persist_expected[0] > 0 || p->persist_expected[1] > 0;
+  if (check_persist) HIPCHK(c, hipMemcpyAsync(sl, p->slice_status.p, sizeof sl, hipMemcpyDeviceToHost, s));
   HIPCHK(c, hipStreamSynchronize(s));
+  // a persistent launch must have finished every chain it was given: a lost FIFO entry or a chain that was parked and
+  // never taken up again would otherwise leave stale rows in the tables
+  for (int ph = 0; ph < 2 && check_persist; ++ph) {
+    if (p->persist_expected[ph] <= 0) continue;
+    if (sl[2 * ph] != 0 || (long long)sl[2 * ph + 1] != p->persist_expected[ph])
+      return set_err(c, ABN_ERR_HIP, std::string("persistent fit launch of phase ") + (ph ? "B" : "A") + " finished " +
+                                         std::to_string(sl[2 * ph + 1]) + " of " + std::to_string(p->persist_expected[ph]) +
+                                         " chains (error word " + std::to_string(sl[2 * ph]) + "): results are incomplete");
+  }
   if (best_start) {
     if (p->ran_a) std::copy(bs.begin(), bs.end(), best_start);
     else std::fill(best_start, best_start + W, 0);  // model uploaded by the caller (abn_boot_model_run)
@@ -1402,6 +1458,7 @@ extern "C" int abn_plan_device_bytes(abn_plan* p, int64_t* bytes) {
   t += p->simplexA.bytes() + p->bestA.bytes() + p->model.bytes() + p->lse.bytes() + p->bestB.bytes();
   t += p->raw_own.bytes() + p->infoA.bytes() + p->infoB.bytes() + p->best_start.bytes() + p->idx.bytes();
   t += p->dstar.bytes() + p->nm_state.bytes() + p->susp_list.bytes() + p->skipped.bytes() + p->slice_buf.bytes();
+  t += p->slice_status.bytes() + p->wid.bytes();
   t += p->dtopo.tri.bytes() + p->dtopo.tid.bytes();
   *bytes = (int64_t)t;
   return ABN_OK;
@@ -1598,7 +1655,10 @@ static int plan_pairwise(abn_ctx* c, int n, long long L, PairPlan& pp) {
   int wt = 256;
   auto bytes = [&](int w) { return (size_t)3 * a.nb * (bs * w + 4) * sizeof(uint32_t) + red_bytes; };
   while (wt > 4 && bytes(wt) > 40 * 1024) wt >>= 1;
-  if (bytes(wt) > 64 * 1024) return set_err(c, ABN_ERR_INVALID_ARG, "too many samples for one LDS tile");
+  // ... up to the CU's whole LDS for very many samples (the launch opts in with hipFuncAttributeMaxDynamicSharedMemorySize):
+  // one tile of four words per sample holds ~2700 samples (the reference's DMatrix::from has no limit; beyond that the
+  // planes of one tile no longer fit a workgroup)
+  if (bytes(wt) > kMaxDynLds) return set_err(c, ABN_ERR_INVALID_ARG, "too many samples for one LDS tile (> ~2700)");
   // ... and small enough that every workgroup sees a few tiles
   while (wt > 32 && (L + 32ll * wt - 1) / (32ll * wt) < 256LL * 4) wt >>= 1;
   a.WT = wt;

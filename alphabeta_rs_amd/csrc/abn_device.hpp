@@ -54,6 +54,7 @@ constexpr int ST_DONE = 12;
 constexpr int kParkHead = 0, kParkTail = 64, kParkAvail = 128, kParkHeaderInts = 192;  // one cache line each
 constexpr int kParkShards = 64;  // independent FIFOs (workgroup b uses b mod 64): a cache line serves ~100 M atomics/s
 constexpr int kFitSuspended = 4;  // internal status between the two passes of a long chain
+constexpr unsigned kSliceErrLostEntry = 1u;  // FitArgs::slice_status[0]
 
 struct FitInfoDev {  // layout of abn_fit_info (include/abneutral.h)
   double best_cost;
@@ -98,6 +99,7 @@ struct FitArgs {
   //   G (explicit lanes_per_chain, packed kernels only) or G | 3 << 8 (streamed pedigrees): G accumulators, one per
   //     lane, xor-butterfly 1, 2, 4, ... (group_sum_dpp).
   int tree;
+  int strict;            // host dispatch only: the STRICT instantiation (serial row-order sum; `tree` is then 1)
   // chains: W windows x C chains
   int W, C;
   int max_iters;
@@ -133,6 +135,10 @@ struct FitArgs {
   unsigned park_cap;     // entries of parked[] PER SHARD (kParkShards shards, each with its own three counters)
   unsigned* park_ht;
   int* parked;
+  // persistent launches: slice_status[0] |= kSliceErrLostEntry when a claimed FIFO entry never appeared (the group goes
+  // idle, the chain's outputs stay unwritten), slice_status[1] += chains finished (results written).  The host compares
+  // the count with W x C after a time-sliced launch: a lost or never-resumed chain is an error, not stale output.
+  unsigned* slice_status;
   double sd_tol;
   double gap_tol;        // 64 * sd_tol, precomputed on the host so that it stays a scalar (kernarg) operand
   // outputs (fit order)
@@ -566,6 +572,26 @@ __device__ __forceinline__ double tree64_finish(const double (&acc)[kWave / G]) 
   return tree64_tail8(v);
 }
 
+// acc + t[0] + t[1] + ... + t[n-1], added in that order (strict order).  t is 16-byte aligned; every lane of a group reads
+// the same addresses (LDS broadcast), eight terms per batch of loads.
+__device__ __forceinline__ double serial_sum_lds(const double* t, int n, double acc) {
+  const f64x2_lds* v = reinterpret_cast<const f64x2_lds*>(t);
+  int i = 0;
+  for (; i + 8 <= n; i += 8) {
+    const f64x2_lds a0 = v[i / 2], a1 = v[i / 2 + 1], a2 = v[i / 2 + 2], a3 = v[i / 2 + 3];
+    acc = acc + a0[0];
+    acc = acc + a0[1];
+    acc = acc + a1[0];
+    acc = acc + a1[1];
+    acc = acc + a2[0];
+    acc = acc + a2[1];
+    acc = acc + a3[0];
+    acc = acc + a3[1];
+  }
+  for (; i < n; ++i) acc = acc + t[i];
+  return acc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The fit kernel.  RMAX > 0 ("resident", needs N <= G*RMAX): the chain's observed divergences
 // (bootstrap: pred_i + resid[idx_i], gathered once per fit) are staged in LDS, each lane keeps its
@@ -574,7 +600,13 @@ __device__ __forceinline__ double tree64_finish(const double (&acc)[kWave / G]) 
 // index row is re-streamed from HBM, coalesced).
 // LDS per workgroup: 64/G chains x (kPw (T+1) + KP + 4 [+ NP]) doubles.
 // ------------------------------------------------------------------------------------------------
-template <int G, int RMAX, bool TWOPASS = false>
+// STRICT (abn_options.strict_order): the residuals are summed SERIALLY in row order — the reference's `square_sum += ...`
+// (src/structs.rs:206-213), the oracle's lanes = 1 — instead of with the tree: the lanes write their rows' terms to LDS
+// (resident: N more doubles per chain; stream: chunks of 8 G rows) and every lane of the group adds them up in order
+// (same address in the whole group: an LDS broadcast).  N dependent additions per evaluation: the price of an opt-in mode.
+constexpr int kStrictRowsPerLane = 8;  // rows per lane and chunk of the strict stream variant
+
+template <int G, int RMAX, bool TWOPASS = false, bool STRICT = false>
 __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)) void abn_fit_kernel(const FitArgs a) {
   // RMAX == 0: stream mode for long rows (deep loop, kStreamWaves wavefronts per SIMD); RMAX == -1: stream mode for
   // mid-size pedigrees whose rows never fill the deep loop (pairs of blocks, three wavefronts per SIMD)
@@ -626,6 +658,8 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
   uint32_t tidp[(RR + 1) / 2];  // two 16-bit triple ids per register
   const bool canon = !STREAM && a.tree == kTreeCanon;  // the canonical 64-accumulator tree (FitArgs::tree), else G accumulators
   uint32_t* tri_s = reinterpret_cast<uint32_t*>(dobs + ((N + 1) & ~1));  // this chain's copy of the triple list
+  // strict order: the rows' terms (resident: behind the triple list, N doubles; stream: behind the constants, 8 G doubles)
+  double* term = STREAM ? dobs : reinterpret_cast<double*>(tri_s) + (((K + 1) / 2 + 1) & ~1);
   if (!STREAM) {
     for (int t = gl; t < K; t += G) tri_s[t] = a.tri[t];
 #pragma unroll
@@ -725,7 +759,11 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
           const double term = r * r + pen;
           x[q] = ((gl + G * (q0 + q)) < N) ? term : 0.0;     // x + 0.0 == x bit for bit (no sum is -0.0)
         }
-        if (canon) {                                         // uniform: row gl + G q belongs to accumulator gl + G (q mod NA)
+        if constexpr (STRICT) {
+#pragma unroll
+          for (int q = 0; q < RC; ++q)
+            if ((gl + G * (q0 + q)) < N) term[gl + G * (q0 + q)] = x[q];
+        } else if (canon) {                                  // uniform: row gl + G q belongs to accumulator gl + G (q mod NA)
 #pragma unroll
           for (int q = 0; q < RC; ++q) av[(q0 + q) % NA] = av[(q0 + q) % NA] + x[q];
         } else {
@@ -733,10 +771,34 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
           for (int q = 0; q < RC; ++q) acc = acc + x[q];
         }
       }
-      if (canon) {
+      if constexpr (STRICT) {                                // `square_sum += ...` in row order, src/structs.rs:206-213
+        __syncthreads();
+        acc = serial_sum_lds(term, N, 0.0);
+        summed = true;
+      } else if (canon) {
         acc = tree64_finish<G>(av);                          // P5, the pedigree's tree
         summed = true;
       }
+    } else if constexpr (STRICT) {
+      // strict stream mode: chunks of 8 G rows — lane l computes rows base + l + G q (coalesced 8-byte loads), the terms
+      // go to LDS and every lane adds them up in row order
+      constexpr int CH = kStrictRowsPerLane * G;
+      for (int base = 0; base < N; base += CH) {
+        const int cnt = (N - base) < CH ? (N - base) : CH;
+#pragma unroll
+        for (int q = 0; q < kStrictRowsPerLane; ++q) {
+          const int i = base + gl + G * q;
+          if (i < N) {
+            const double dd = (a.dmode == 1) ? a.pred[wN + i] + a.resid[wN + idx_row[i]] : a.D[dN + i];
+            const double r = dd - ic - dtab[a.tid[i]];
+            term[gl + G * q] = r * r + pen;
+          }
+        }
+        __syncthreads();
+        acc = serial_sum_lds(term, cnt, acc);
+        __syncthreads();
+      }
+      summed = true;
     } else {
       // stream mode.  Lane l owns row blocks of kStreamVec = 4 consecutive rows: rows 4(l + G q) .. +3 for
       // q = 0, 1, ... — so the u32 index row is read with one 16-byte load per lane (1 KiB per wavefront
@@ -1021,7 +1083,7 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
       fo.iters = iter;
       fo.evals = evals;
       fo.status = fin_status;
-      fo.lanes = STREAM ? (G | ((kStreamVec - 1) << 8)) : a.tree;  // reduction-tree code (oracle: `lanes`)
+      fo.lanes = STRICT ? 1 : (STREAM ? (G | ((kStreamVec - 1) << 8)) : a.tree);  // reduction-order code (oracle: `lanes`)
       a.info[chain] = fo;
     }
     if (a.raw) {
@@ -1104,6 +1166,7 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
   int fin_status = 2;
   int q_start = 0;           // time slicing: evals of this chain when its current quantum began
   bool fresh_done = false;   // this group has seen the queue of unstarted chains empty
+  unsigned n_written = 0;    // fits this group has finished (results written): summed into slice_status[1] at the end
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     vx[k] = 0.0;
@@ -1294,13 +1357,20 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
     else if (best_cost <= -__builtin_inf()) status = 3;
     // time slicing: the quantum is used up and somebody is waiting (an unstarted or a parked chain) -> park.
     // The counters are read once per quantum; a stale answer costs at most a park that is taken up again at once.
+    // The counters change under the group's feet (other CUs): ONE lane reads them and the group takes its verdict —
+    // lanes that each read for themselves could disagree at a 0/1 boundary and tear the chain apart.  (evals, q_start
+    // and status are replicated in the group, so all its lanes are here together and the leader lane is active.)
     bool suspend = false;
     if (a.quantum > 0 && status < 0 && evals - q_start >= a.quantum) {
-      const unsigned fq = __hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int av = __hip_atomic_load(reinterpret_cast<int*>(pht) + kParkAvail, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned tl = __hip_atomic_load(pht + kParkTail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      suspend = (gridDim.x * NG + fq < total || av > 0) && tl + gridDim.x * NG / kParkShards + NG < a.park_cap;
+      int verdict = 0;
+      if (gl == 0) {
+        const unsigned fq = __hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int av = __hip_atomic_load(reinterpret_cast<int*>(pht) + kParkAvail, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned tl = __hip_atomic_load(pht + kParkTail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        verdict = ((gridDim.x * NG + fq < total || av > 0) && tl + gridDim.x * NG / kParkShards + NG < a.park_cap) ? 1 : 0;
+      }
+      suspend = __builtin_amdgcn_ds_bpermute(4 * (g * G), verdict) != 0;  // the group leader's reading
       q_start = evals;
     }
     const bool done = status >= 0 || suspend;
@@ -1412,6 +1482,7 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
           sd(31, __longlong_as_double(have_best ? 1ll : 0ll));
         }
       } else if (fin) {
+        n_written += 1u;
         if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
         if (gl == 0) {
           FitInfoDev fo;
@@ -1431,11 +1502,15 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
         }
       }
       if (a.quantum > 0) {
-        // publish the parked chains of this wavefront: the state stores (written through to memory) have completed
-        // before the entry is stored — a wavefront-level wait, NOT an agent-scope fence: that would write back and
-        // invalidate the XCD's whole L2 at every park (measured: a 5 ms launch took 2 s).  All of this wavefront's
-        // entries are out before any of its groups looks for one (no group can wait for an entry of its own wavefront).
-        if (__ballot(parking) != 0ull) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // Publish the parked chains of this wavefront.  The state stores above are write-through (agent scope, sc1) and
+        // the vector-memory counter of gfx9 retires in order, so once vmcnt reaches 0 every one of them has been
+        // acknowledged past this XCD's L2 — only then may the FIFO entry (another sc1 store) become visible to a group on
+        // another XCD.  The wait is EXPLICIT: a workgroup-scope release fence emits no instruction here (one wavefront
+        // per workgroup), and an agent-scope fence would write back and invalidate the XCD's whole L2 at every park
+        // (measured: a 5 ms launch took 2 s).  tests/test_isa_checks.py greps the emitted ISA for this wait between the
+        // state stores and the entry store.  All of this wavefront's entries are out before any of its groups looks for
+        // one (no group can wait for an entry of its own wavefront).
+        if (__ballot(parking) != 0ull) asm volatile("s_waitcnt vmcnt(0) ; abn: parked state written through" ::: "memory");
         if (parking && gl == 0) {
           const unsigned pos = atomicAdd(pht + kParkTail, 1u);
           __hip_atomic_store(pk + pos, (int)chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1455,14 +1530,22 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
           int* avail = reinterpret_cast<int*>(pht) + kParkAvail;
           if (atomicSub(avail, 1) > 0) {
             const unsigned h = atomicAdd(pht + kParkHead, 1u);
-            int cpk;  // entries are published in any order: the one of this ticket may be a few instructions away
-            unsigned spins = 0;  // (its writer is a running wavefront past its reservation; bounded all the same: a
-            while ((cpk = __hip_atomic_load(pk + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0) {  // lost entry
-              __builtin_amdgcn_s_sleep(1);                                                                // must fail
-              if (++spins > (1u << 24)) __builtin_trap();                                                 // loudly, not hang)
+            // entries are published in any order: the one of this ticket may be a few instructions away (its writer
+            // is a running wavefront past its reservation).  Bounded all the same: a lost entry must neither hang the
+            // launch nor abort the process (the C-ABI never crashes) — the error word is set, this group goes idle and
+            // abn_plan_download reports ABN_ERR_HIP because the chain's fit was never written.
+            int cpk;
+            unsigned spins = 0;
+            while ((cpk = __hip_atomic_load(pk + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < 0 && spins < (1u << 24)) {
+              __builtin_amdgcn_s_sleep(1);
+              ++spins;
             }
-            nxt = (unsigned)cpk;
-            take_parked = true;
+            if (cpk >= 0) {
+              nxt = (unsigned)cpk;
+              take_parked = true;
+            } else if (a.slice_status) {
+              atomicOr(a.slice_status, kSliceErrLostEntry);
+            }
           } else {
             atomicAdd(avail, 1);
           }
@@ -1481,6 +1564,13 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
       }
       __syncthreads();
     }
+  }
+  // fits finished by this wavefront (n_written is replicated in a group: its leader's copy counts)
+  if (a.slice_status) {
+    unsigned mine = gl == 0 ? n_written : 0u;
+#pragma unroll
+    for (int off = G; off < kWave; off <<= 1) mine += (unsigned)__shfl_xor((int)mine, off, kWave);
+    if (lane == 0 && mine) atomicAdd(a.slice_status + 1, mine);
   }
 }
 

@@ -86,7 +86,18 @@ def run_sharded(compute_shard: Callable[[Shard], "np.ndarray"], n_windows: int, 
         local = torch.as_tensor(np.ascontiguousarray(local), dtype=torch.float64)
     if device is not None:
         local = local.to(device)
-    return gather_tables(local, n_windows, n_boot, group=group), shard
+    full = gather_tables(local, n_windows, n_boot, group=group)
+    # A window without a finite start has NaN rows (abn_plan_download: ABN_ERR_NO_FINITE_FIT; the reference panics,
+    # src/ab_neutral.rs:28,100).  The verdict is taken from the GATHERED table, so every rank raises together: a rank
+    # that raised before the gather would leave the others waiting in the collective until its watchdog fires.
+    if n_windows * n_boot:
+        dead = torch.isnan(full[:, :, 0]).all(dim=1)
+        if bool(dead.any().item()):
+            from . import AbnError
+
+            ws = [int(w) for w in torch.nonzero(dead).flatten().tolist()]
+            raise AbnError(5, f"{len(ws)} window(s) have no finite start (NaN rows): {ws[:8]}{'...' if len(ws) > 8 else ''}")
+    return full, shard
 
 
 def hip_shard_runner(ctx, generations, d_obs, p0uu, n_starts, options=None):
@@ -94,7 +105,7 @@ def hip_shard_runner(ctx, generations, d_obs, p0uu, n_starts, options=None):
     torch tensor (no copy before the RCCL gather)."""
     import torch
 
-    from . import AbnError, Plan
+    from . import Plan
 
     d_obs = np.asarray(d_obs, dtype=np.float64)
     p0uu = np.asarray(p0uu, dtype=np.float64)
@@ -110,10 +121,9 @@ def hip_shard_runner(ctx, generations, d_obs, p0uu, n_starts, options=None):
         plan.set_windows(d_obs[w0:w0 + wn], p0uu[w0:w0 + wn])
         plan.run()
         plan.sync()
-        failed = plan.failed_windows()
-        plan.close()
-        if failed:  # the reference panics (src/ab_neutral.rs:28,100); never gather NaN tables silently
-            raise AbnError(5, f"{failed} window(s) of the shard [{w0}, {w0 + wn}) have no finite start")
+        run.failed_windows = plan.failed_windows()   # local count, for logging; run_sharded raises on EVERY rank after
+        plan.close()                                  # the gather (the failed windows' rows are NaN)
         return raw
 
+    run.failed_windows = 0
     return run

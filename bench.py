@@ -200,10 +200,10 @@ def pcie_inclusive(A, ctx, wl, opts, reps=5):
             "what": "abn_ab_neutral_run + abn_boot_model_run on host buffers, end to end"}
 
 
-def quick_workload(A, ctx, name, seed, steps=3):
+def quick_workload(A, ctx, name, seed, steps=3, **options):
     """a few steps of another BASELINE configuration on this GPU, so that its number is driver-run too"""
     wl = make_workload(name, 0, 1)
-    plan = A.Plan(ctx, wl["gens"], wl["wr"], wl["S"], wl["B"], options=A.default_options(seed=seed))
+    plan = A.Plan(ctx, wl["gens"], wl["wr"], wl["S"], wl["B"], options=A.default_options(seed=seed, **options))
     plan.set_windows(wl["D"], wl["p0"])
     plan.run()
     plan.sync()
@@ -362,6 +362,10 @@ def main():
     ap.add_argument("--execute-stuck-fits", action="store_true",
                     help="abn_options.no_fixed_point_skip = 1: execute the repeated iterations of fits that have reached "
                          "argmin's fixed point, as the reference does (same outputs; default: finish them at once)")
+    ap.add_argument("--strict-order", action="store_true",
+                    help="abn_options.strict_order = 1: every cost sums its residuals serially in row order, as the "
+                         "reference does (src/structs.rs:206-213); fits are then bit-equal to the oracle's lanes = 1. "
+                         "The default line reports the price of this mode as `strict_order`")
     ap.add_argument("--no-stream-probe", action="store_true",
                     help="skip the short C5-shard run that measures the stream-mode kernel against the HBM roof")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -436,7 +440,7 @@ def main():
     N, Wr, S, B = wl["gens"].shape[0], wl["wr"], wl["S"], wl["B"]
     stream = torch.cuda.current_stream().cuda_stream
     ctx = A.Context(local_rank, stream=stream)
-    opts = A.default_options(seed=seed, lanes_per_chain=args.lanes,
+    opts = A.default_options(seed=seed, lanes_per_chain=args.lanes, strict_order=1 if args.strict_order else 0,
                              no_fixed_point_skip=1 if args.execute_stuck_fits else 0)
     by_boot = wl.get("shard") == "bootstraps"
     plan = A.Plan(ctx, wl["gens"], Wr, S, B, window_offset=0 if by_boot else rank * Wr,
@@ -570,6 +574,7 @@ def main():
             "fits_per_step": tot_fits, "evals_per_step": tot_evals, "nm_iters_per_step": tot_iters,
             "evals_not_executed_per_step": tot_skipped,
             "fixed_point_skip": not args.execute_stuck_fits,
+            "strict_order_run": bool(args.strict_order),
             "kernel_ms": kms,
             "roofline": roofline,
         }
@@ -582,6 +587,12 @@ def main():
                 result["pcie_inclusive"] = pcie_inclusive(A, ctx, wl, opts)
             result["extra_workloads"] = {n: quick_workload(A, ctx, n, seed) for n in ("c2", "c4", "g351")
                                          if n != args.workload}
+            if not args.strict_order:   # what the reference's summation order costs on this workload
+                so = quick_workload(A, ctx, args.workload, seed, strict_order=1)
+                so["price"] = fits_per_s / so["fits_per_s"]
+                so["what"] = ("abn_options.strict_order = 1 (serial row-order residual sums, bit-equal to the oracle's "
+                              "lanes = 1); price = default fits/s / strict fits/s")
+                result["strict_order"] = so
             result["pairwise"] = pairwise_bench(A, ctx)
         if not args.no_cpu_baseline and world == 1:   # the CPU baseline is a one-GPU (rank 0) measurement
             bs = int(out["best_start"][0])

@@ -94,6 +94,7 @@ def lib() -> C.CDLL:
         L.abo_boot_model.argtypes = [dp, C.c_int, dp, dp, dp, C.c_double, C.c_double, C.c_double, C.c_uint64,
                                      C.c_uint32, C.c_uint32, C.c_int64, C.c_int, C.c_double, C.c_int, C.c_int,
                                      C.c_int, C.c_int, dp, C.c_void_p]
+        L.abo_boot_model_trace.argtypes = L.abo_boot_model.argtypes + [C.POINTER(C.c_uint8), C.c_int]
         L.abo_analyze.argtypes = [dp, C.c_int64, dp]
         L.abo_pairwise_divergence.argtypes = [C.POINTER(C.c_uint8), dp, C.c_int, C.c_int64, C.c_double,
                                               C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), dp]
@@ -228,6 +229,20 @@ def boot_model(ped, model, pred, resid, p_uu, eqp, eqp_weight, seed, window, b0,
                          window, b0, nb, max_iters, sd_tol, shrink_variant, lanes, int(table), threads, _dp(raw),
                          res.ctypes.data)
     return raw, res
+
+
+def boot_model_trace(ped, model, pred, resid, p_uu, eqp, eqp_weight, seed, window, b0, nb, max_iters=1000, sd_tol=EPS,
+                     shrink_variant=0, lanes=1, table=True, threads=0):
+    """boot_model plus the branch every Nelder-Mead iteration took: (raw, results, traces[nb, max_iters] u8;
+    0 reflection accepted, 1 expansion tried, 2 contraction accepted, 3 contraction rejected, 4 shrink)."""
+    ped, model, pred, resid = _f64(ped), _f64(model), _f64(pred), _f64(resid)
+    raw = np.empty((nb, 7))
+    res = np.zeros(nb, dtype=FIT_DTYPE)
+    tr = np.full((nb, max_iters), 255, dtype=np.uint8)
+    lib().abo_boot_model_trace(_dp(ped), ped.shape[0], _dp(model), _dp(pred), _dp(resid), p_uu, eqp, eqp_weight, seed,
+                               window, b0, nb, max_iters, sd_tol, shrink_variant, lanes, int(table), threads, _dp(raw),
+                               res.ctypes.data, tr.ctypes.data_as(C.POINTER(C.c_uint8)), max_iters)
+    return raw, res, tr
 
 
 def analyze(raw):

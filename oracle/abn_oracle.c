@@ -326,9 +326,12 @@ static void nm_update_best(const nm_vertex* v0, double* best_cost, double best[4
   }
 }
 
-void abo_fit(const double* ped, int n, const double* dobs, double p_uu, double eqp,
-             double eqp_weight, const double simplex0[20], int max_iters, double sd_tol,
-             int shrink_on_failed_contraction, int lanes, int table, abo_fit_result* out) {
+/* trace (nullable, trace_cap entries): the branch next_iter took in iteration i — 0 reflection accepted, 1 expansion
+ * tried, 2 contraction accepted, 3 contraction rejected, 4 shrink.  Scheduling studies only (scripts/sched_sim.py). */
+static void fit_impl(const double* ped, int n, const double* dobs, double p_uu, double eqp,
+                     double eqp_weight, const double simplex0[20], int max_iters, double sd_tol,
+                     int shrink_on_failed_contraction, int lanes, int table, abo_fit_result* out,
+                     uint8_t* trace, int trace_cap) {
   nm_problem pb = {ped, n, dobs, p_uu, eqp, eqp_weight, lanes, table, 0};
   nm_vertex v[5];
   /* Solver::init: evaluate all vertices in the given order, sort */
@@ -375,10 +378,12 @@ void abo_fit(const double* ped, int n, const double* dobs, double p_uu, double e
     }
     for (int d = 0; d < 4; ++d) xr[d] = x0[d] + (x0[d] - v[4].x[d]) * 1.0;
     double fr = nm_cost(&pb, xr);
+    int kind = 0;
     if (fr < v[3].c && fr >= v[0].c) {
       memcpy(v[4].x, xr, sizeof xr);
       v[4].c = fr;
     } else if (fr < v[0].c) {
+      kind = 1;
       double xe[4];
       for (int d = 0; d < 4; ++d) xe[d] = x0[d] + (xr[d] - x0[d]) * 2.0;
       double fe = nm_cost(&pb, xe);
@@ -393,16 +398,20 @@ void abo_fit(const double* ped, int n, const double* dobs, double p_uu, double e
       double xc[4];
       for (int d = 0; d < 4; ++d) xc[d] = x0[d] + (v[4].x[d] - x0[d]) * 0.5;
       double fc = nm_cost(&pb, xc);
+      kind = 3;
       if (fc < v[4].c) {
+        kind = 2;
         memcpy(v[4].x, xc, sizeof xc);
         v[4].c = fc;
       } else if (shrink_on_failed_contraction) {
+        kind = 4;
         for (int k = 1; k < 5; ++k) {
           for (int d = 0; d < 4; ++d) v[k].x[d] = v[0].x[d] + (v[k].x[d] - v[0].x[d]) * 0.5;
           v[k].c = nm_cost(&pb, v[k].x);
         }
       }
     } else { /* only reachable when fr is NaN */
+      kind = 4;
       for (int k = 1; k < 5; ++k) {
         for (int d = 0; d < 4; ++d) v[k].x[d] = v[0].x[d] + (v[k].x[d] - v[0].x[d]) * 0.5;
         v[k].c = nm_cost(&pb, v[k].x);
@@ -410,6 +419,7 @@ void abo_fit(const double* ped, int n, const double* dobs, double p_uu, double e
     }
     nm_sort(v);
     nm_update_best(&v[0], &best_cost, best, &have_best);
+    if (trace && iter < trace_cap) trace[iter] = (uint8_t)kind;
     ++iter;
   }
   memcpy(out->best, best, sizeof best);
@@ -418,6 +428,13 @@ void abo_fit(const double* ped, int n, const double* dobs, double p_uu, double e
   out->evals = pb.evals;
   out->status = have_best ? status : ABO_FIT_NONFINITE;
   out->pad = 0;
+}
+
+void abo_fit(const double* ped, int n, const double* dobs, double p_uu, double eqp,
+             double eqp_weight, const double simplex0[20], int max_iters, double sd_tol,
+             int shrink_on_failed_contraction, int lanes, int table, abo_fit_result* out) {
+  fit_impl(ped, n, dobs, p_uu, eqp, eqp_weight, simplex0, max_iters, sd_tol, shrink_on_failed_contraction, lanes, table,
+           out, NULL, 0);
 }
 
 void abo_fit_batch(const double* ped, int n, const double* dobs_rows, int64_t f, double p_uu,
@@ -564,11 +581,11 @@ void abo_boot_simplex(uint64_t seed, uint32_t window, uint32_t boot, const doubl
 }
 
 /* src/boot_model.rs:41-100 */
-void abo_boot_model(const double* ped, int n, const double model[4], const double* pred,
+static void boot_model_impl(const double* ped, int n, const double model[4], const double* pred,
                     const double* resid, double p_uu, double eqp, double eqp_weight, uint64_t seed,
                     uint32_t window, uint32_t b0, int64_t nb, int max_iters, double sd_tol,
                     int shrink_on_failed_contraction, int lanes, int table, int threads,
-                    double* raw, abo_fit_result* results) {
+                    double* raw, abo_fit_result* results, uint8_t* traces, int trace_cap) {
 #ifdef _OPENMP
   if (threads <= 0) threads = omp_get_max_threads();
 #pragma omp parallel num_threads(threads)
@@ -586,14 +603,33 @@ void abo_boot_model(const double* ped, int n, const double model[4], const doubl
       double simplex[20];
       abo_boot_simplex(seed, window, b, model, simplex);
       abo_fit_result r;
-      abo_fit(ped, n, dstar, p_uu, eqp, eqp_weight, simplex, max_iters, sd_tol,
-              shrink_on_failed_contraction, lanes, table, &r);
+      fit_impl(ped, n, dstar, p_uu, eqp, eqp_weight, simplex, max_iters, sd_tol,
+               shrink_on_failed_contraction, lanes, table, &r, traces ? traces + (size_t)i * (size_t)trace_cap : NULL,
+               trace_cap);
       abo_bootstrap_row(r.best, raw + 7 * i);
       if (results) results[i] = r;
     }
     free(idx);
     free(dstar);
   }
+}
+
+void abo_boot_model(const double* ped, int n, const double model[4], const double* pred,
+                    const double* resid, double p_uu, double eqp, double eqp_weight, uint64_t seed,
+                    uint32_t window, uint32_t b0, int64_t nb, int max_iters, double sd_tol,
+                    int shrink_on_failed_contraction, int lanes, int table, int threads,
+                    double* raw, abo_fit_result* results) {
+  boot_model_impl(ped, n, model, pred, resid, p_uu, eqp, eqp_weight, seed, window, b0, nb, max_iters, sd_tol,
+                  shrink_on_failed_contraction, lanes, table, threads, raw, results, NULL, 0);
+}
+/* the same, recording every fit's branch per iteration (traces[nb][trace_cap]; see fit_impl) */
+void abo_boot_model_trace(const double* ped, int n, const double model[4], const double* pred,
+                          const double* resid, double p_uu, double eqp, double eqp_weight, uint64_t seed,
+                          uint32_t window, uint32_t b0, int64_t nb, int max_iters, double sd_tol,
+                          int shrink_on_failed_contraction, int lanes, int table, int threads,
+                          double* raw, abo_fit_result* results, uint8_t* traces, int trace_cap) {
+  boot_model_impl(ped, n, model, pred, resid, p_uu, eqp, eqp_weight, seed, window, b0, nb, max_iters, sd_tol,
+                  shrink_on_failed_contraction, lanes, table, threads, raw, results, traces, trace_cap);
 }
 
 /* ------------------------------------------------------------------------------------------------

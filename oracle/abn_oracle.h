@@ -126,6 +126,14 @@ void abo_boot_model(const double* ped, int n, const double model[4], const doubl
                     int shrink_on_failed_contraction, int lanes, int table, int threads,
                     double* raw, abo_fit_result* results);
 
+/* abo_boot_model that also records the branch every Nelder-Mead iteration took (traces[nb][trace_cap] bytes: 0 reflection
+ * accepted, 1 expansion tried, 2 contraction accepted, 3 contraction rejected, 4 shrink): scheduling studies only */
+void abo_boot_model_trace(const double* ped, int n, const double model[4], const double* pred,
+                          const double* resid, double p_uu, double eqp, double eqp_weight, uint64_t seed,
+                          uint32_t window, uint32_t b0, int64_t nb, int max_iters, double sd_tol,
+                          int shrink_on_failed_contraction, int lanes, int table, int threads,
+                          double* raw, abo_fit_result* results, uint8_t* traces, int trace_cap);
+
 /* src/analysis.rs:50-98: out[24] = 8 means, 8 sample SDs, 8 x (lo,hi)... laid out as
  * mean[8] (alpha,beta,beta/alpha,weight,intercept,pr_mm,pr_um,pr_uu), sd[8], ci_lo[8], ci_hi[8] -> 32 */
 void abo_analyze(const double* raw, int64_t b, double out[32]);

@@ -87,6 +87,51 @@ def test_gloo_shard_and_gather_matches_unsharded(world, W, B, mode):
     assert ok and got_mode == mode and shape == (W, B, 7)
 
 
+def _failing_worker(rank, world, port, q):
+    sys.path.insert(0, str(ROOT))
+    import torch.distributed as dist
+
+    import alphabeta_rs_amd as A
+    from alphabeta_rs_amd import distributed as D_
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def compute(shard):  # window 2 (on the last rank) has no finite start: its rows are NaN, as the plan writes them
+        out = np.full((shard.n_windows, shard.n_boot, 7), float(shard.window_offset + 1))
+        for i in range(shard.n_windows):
+            if shard.window_offset + i == 2:
+                out[i] = np.nan
+        return out
+
+    try:
+        D_.run_sharded(compute, 3, 4)
+        q.put((rank, "no error"))
+    except A.AbnError as e:
+        q.put((rank, f"AbnError {e.status}"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failed_window_raises_on_every_rank():
+    """a rank that raised before the gather left the others blocked in the collective.  Now the NaN rows
+    travel through the gather and every rank raises ABN_ERR_NO_FINITE_FIT together."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, "AbnError 5"), (1, "AbnError 5")]
+
+
 def test_reduction_tree_is_a_function_of_the_pedigree_only(abn):
     """abn_reduction_tree takes generations and options — no fit counts: the tree cannot change with sharding.
     Auto: the canonical 64-accumulator tree (0x10040) for every LDS-resident pedigree, whatever lane count its packed
