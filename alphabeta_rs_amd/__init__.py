@@ -33,6 +33,7 @@ STATUS_NAMES = {
     6: "ABN_ERR_STATE",
 }
 FIT_CONVERGED, FIT_MAX_ITERS, FIT_NONFINITE, FIT_TARGET = 0, 1, 2, 3
+KERNEL_NAMES = {0: "none", 1: "speculative", 2: "resident", 3: "persistent", 4: "stream", 5: "two_pass"}
 
 FIT_INFO_DTYPE = np.dtype(
     [("best_cost", "<f8"), ("iters", "<i4"), ("evals", "<i4"), ("status", "<i4"), ("lanes", "<i4")]
@@ -50,7 +51,7 @@ EXPORTED_SYMBOLS = [
     "abn_multi_create", "abn_multi_destroy", "abn_multi_last_error", "abn_multi_set_windows", "abn_multi_run",
     "abn_multi_sync", "abn_multi_shard", "abn_multi_raw_device_ptr", "abn_multi_download", "abn_multi_counters",
     "abn_multi_rccl_available", "abn_reduction_tree", "abn_pairwise_divergence_dev", "abn_multi_set_window_ids",
-    "abn_multi_plan_shard",
+    "abn_multi_plan_shard", "abn_plan_last_kernels", "abn_multi_kernel_ms",
 ]
 
 
@@ -135,6 +136,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     L.abn_plan_device_bytes.argtypes = [vp, C.POINTER(C.c_int64)]
     L.abn_plan_set_window_ids.argtypes = [vp, u32p]
     L.abn_plan_failed_windows.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.abn_plan_last_kernels.argtypes = [vp, C.POINTER(C.c_int32)]
     i32p = C.POINTER(C.c_int32)
     L.abn_multi_create.argtypes = [i32p, C.c_int32, op, dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.abn_multi_destroy.argtypes = [vp]
@@ -147,6 +149,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     L.abn_multi_shard.argtypes = [vp, C.c_int32, i32p]
     L.abn_multi_plan_shard.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p]
     L.abn_multi_raw_device_ptr.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    L.abn_multi_kernel_ms.argtypes = [vp, C.c_int32, dp]
     L.abn_multi_download.argtypes = [vp, dp, dp, dp, dp, vp, vp, i32p]
     L.abn_multi_counters.argtypes = [vp, C.POINTER(C.c_int64)]
     L.abn_multi_rccl_available.argtypes = [C.POINTER(C.c_int)]
@@ -457,6 +460,12 @@ class Plan:
         self.ctx._check(self._L.abn_plan_device_bytes(self._h, C.byref(b)))
         return b.value
 
+    def last_kernels(self):
+        """which fit kernel the last run of each phase used (ABN_KERNEL_* names) and its lanes per chain"""
+        out = (C.c_int32 * 4)()
+        self.ctx._check(self._L.abn_plan_last_kernels(self._h, out))
+        return {"starts": (KERNEL_NAMES.get(out[0], out[0]), out[1]), "boot": (KERNEL_NAMES.get(out[2], out[2]), out[3])}
+
 
 def reduction_tree(generations, options: Options | None = None) -> int:
     """The residual reduction tree of a pedigree (abn_fit_info.lanes): host arithmetic, no device needed."""
@@ -534,6 +543,11 @@ class MultiPlan:
 
     def sync(self):
         self._check(self._L.abn_multi_sync(self._h))
+
+    def kernel_ms(self, device_index: int = 0):
+        ms = np.zeros(3)
+        self._check(self._L.abn_multi_kernel_ms(self._h, device_index, _dp(ms)))
+        return {"fit_starts": ms[0], "select": ms[1], "fit_boot": ms[2]}
 
     def shard(self, device_index: int):
         out = (C.c_int32 * 4)()

@@ -312,9 +312,9 @@ static hipError_t launch_fit_g(const FitArgs& a, int rmax, dim3 grid, size_t lds
 
 // `a.chain_stride` must be the topology's scratch stride (kPw*TP + KP + 4, even); the resident variant adds an even
 // number of doubles (observations + triple list): every chain's region stays 16-byte aligned for load_matrix.
-// persistent (nullable): set to true when the launch ran abn_fit_refill_kernel (a.slice_status then counts its fits)
-static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, bool* persistent = nullptr) {
-  if (persistent) *persistent = false;
+// kind (nullable): the ABN_KERNEL_* code of what was launched (PERSISTENT: a.slice_status then counts its fits)
+static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, int* kind = nullptr) {
+  if (kind) *kind = ABN_KERNEL_NONE;
   const long long chains = (long long)a.W * a.C;
   if (chains <= 0) return ABN_OK;
   const int ng = kWave / lanes;
@@ -352,7 +352,10 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, bool* pe
   if (refill) blocks = kPersistWaves;
   if (!refill) a.quantum = 0;
   if (refill && a.slice_status) HIPCHK(c, hipMemsetAsync(a.slice_status, 0, 2 * sizeof(unsigned), st));
-  if (persistent) *persistent = refill;
+  if (kind)
+    *kind = refill ? ABN_KERNEL_PERSISTENT
+            : rmax <= 0 ? ABN_KERNEL_STREAM
+            : (a.iter_cap > 0 || a.resume != 0) ? ABN_KERNEL_TWO_PASS : ABN_KERNEL_RESIDENT;
   if (a.quantum > 0) {  // empty FIFO of parked chains: entries -1, head = tail = 0
     HIPCHK(c, hipMemsetAsync(a.parked, 0xff, (size_t)kParkShards * a.park_cap * sizeof(int), st));
     HIPCHK(c, hipMemsetAsync(a.park_ht, 0, (size_t)kParkShards * kParkHeaderInts * sizeof(unsigned), st));
@@ -833,6 +836,7 @@ struct abn_plan {
   unsigned slice_cap = 0;
   DevBuf<unsigned> slice_status;   // per phase: error word, fits finished by the persistent kernel (FitArgs::slice_status)
   long long persist_expected[2] = {0, 0};  // chains the last persistent launch of phase A / B had to finish (0: none)
+  int32_t last_kernels[4] = {0, 0, 0, 0};  // abn_plan_last_kernels
   bool stream_b = false;
   double* raw = nullptr;  // raw_own.p or caller-bound
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1089,16 +1093,27 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   }
   const bool whole = w0 == 0 && wn == p->W;   // window groups on side streams share the plan's status words: unchecked
   if (whole) a.slice_status = p->slice_status.p;
-  bool persistent = false;
+  int kind = ABN_KERNEL_NONE;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[0], st));
   // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once,
   // a fourth keeps the simplex and prepares the next candidates meanwhile (abn_fit_spec_kernel)
-  const bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && !a.strict &&
-                    (long long)p->W * p->S <= spec_max_chains(p->N) && spec_applicable(a);
+  bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && !a.strict &&
+              (long long)p->W * p->S <= spec_max_chains(p->N) && spec_applicable(a);
+  int lanes_a = p->lanes_a;
+#ifdef ABN_MEASUREMENT_KNOBS  // ABN_PHASE_A_KERNEL = spec | wide | packed  (scripts/phase_a_sweep.py)
+  if (const char* e = getenv("ABN_PHASE_A_KERNEL")) {
+    const bool can_wide = p->opt.lanes_per_chain == 0 && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree);
+    if (!strcmp(e, "spec")) spec = can_wide && !a.strict && spec_applicable(a);
+    if (!strcmp(e, "wide")) { spec = false; if (can_wide) lanes_a = kWave; }
+    if (!strcmp(e, "packed")) { spec = false; lanes_a = p->lanes; }
+  }
+#endif
   int rc;
   if (spec) {
     rc = launch_fit_spec(c, a, st);
+    kind = ABN_KERNEL_SPECULATIVE;
   } else if (p->twopass_a && w0 == 0 && wn == p->W) {
+    kind = ABN_KERNEL_TWO_PASS;
     int* cnt = p->susp_list.p + (size_t)p->W * S;
     HIPCHK(c, hipMemsetAsync(cnt, 0, sizeof(int), st));
     a.state = p->nm_state.p;
@@ -1106,17 +1121,21 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
     a.susp_count = cnt;
     a.iter_cap = kPhaseACap;
     a.resume = 0;
-    rc = launch_fit(c, a, p->lanes_a, st);          // pass 1: everybody, capped
+    rc = launch_fit(c, a, lanes_a, st);             // pass 1: everybody, capped
     if (!rc) {
       a.iter_cap = 0;
       a.resume = 1;
-      rc = launch_fit(c, a, p->lanes_a, st);        // pass 2: the parked chains, to the end
+      rc = launch_fit(c, a, lanes_a, st);           // pass 2: the parked chains, to the end
     }
   } else {
-    rc = launch_fit(c, a, p->lanes_a, st, &persistent);
+    rc = launch_fit(c, a, lanes_a, st, &kind);
   }
   if (rc) return rc;
-  if (whole) p->persist_expected[0] = persistent ? (long long)wn * p->S : 0;
+  if (whole) p->persist_expected[0] = kind == ABN_KERNEL_PERSISTENT ? (long long)wn * p->S : 0;
+  if (timed) {
+    p->last_kernels[0] = kind;
+    p->last_kernels[1] = spec ? kWave : lanes_a;
+  }
   if (timed) HIPCHK(c, hipEventRecord(p->ev[1], st));
   SelectArgs s{};
   s.tri = a.tri;
@@ -1181,7 +1200,7 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   }
   const bool whole = w0 == 0 && wn == p->W;
   if (whole) a.slice_status = p->slice_status.p + 2;
-  bool persistent = false;
+  int kind = ABN_KERNEL_SPECULATIVE;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[4], st));
   if (p->stream_b) {  // gather the bootstrap observations once per fit, then stream them
     double* dst = p->dstar.p + o * B * N;
@@ -1211,9 +1230,13 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
     if (!strcmp(e, "packed")) spec = false;
   }
 #endif
-  int rc = spec ? launch_fit_spec(c, a, st) : launch_fit(c, a, lanes_b, st, &persistent);
+  int rc = spec ? launch_fit_spec(c, a, st) : launch_fit(c, a, lanes_b, st, &kind);
   if (rc) return rc;
-  if (whole) p->persist_expected[1] = persistent ? (long long)wn * p->B : 0;
+  if (whole) p->persist_expected[1] = kind == ABN_KERNEL_PERSISTENT ? (long long)wn * p->B : 0;
+  if (timed) {
+    p->last_kernels[2] = kind;
+    p->last_kernels[3] = spec ? kWave : lanes_b;
+  }
   if (timed) HIPCHK(c, hipEventRecord(p->ev[5], st));
   return ABN_OK;
 }
@@ -1450,6 +1473,12 @@ extern "C" int abn_plan_debug_stamps(abn_plan* p, unsigned long long* out8) { re
 // the same for the speculative three-wavefront kernel (wavefront 0 of chain 0; out8[7] = iterations)
 extern "C" int abn_plan_debug_stamps_spec(abn_plan* p, unsigned long long* out8) { return debug_stamps(p, out8, true); }
 #endif
+
+extern "C" int abn_plan_last_kernels(abn_plan* p, int32_t* out4) {
+  if (!p || !out4) return ABN_ERR_INVALID_ARG;
+  for (int k = 0; k < 4; ++k) out4[k] = p->last_kernels[k];
+  return ABN_OK;
+}
 
 extern "C" int abn_plan_device_bytes(abn_plan* p, int64_t* bytes) {
   if (!p || !bytes) return ABN_ERR_INVALID_ARG;

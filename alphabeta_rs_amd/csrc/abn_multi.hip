@@ -341,6 +341,13 @@ extern "C" int abn_multi_shard(abn_multi* m, int32_t device_index, int32_t* out4
   return ABN_OK;
 }
 
+// HIP-event durations of one device's last run (abn_plan_kernel_ms of its plan): the launches of bench.py's roofline
+extern "C" int abn_multi_kernel_ms(abn_multi* m, int32_t device_index, double* ms3) {
+  if (!m || !ms3 || device_index < 0 || device_index >= m->n) return ABN_ERR_INVALID_ARG;
+  const int rc = abn_plan_kernel_ms(m->plan[(size_t)device_index], ms3);
+  return rc ? plan_fail(m, device_index, rc, "abn_plan_kernel_ms") : ABN_OK;
+}
+
 extern "C" int abn_multi_raw_device_ptr(abn_multi* m, int32_t device_index, void** dev_ptr) {
   if (!m || !dev_ptr || device_index < 0 || device_index >= m->n) return ABN_ERR_INVALID_ARG;
   if (m->gather) {

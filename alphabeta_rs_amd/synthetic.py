@@ -174,3 +174,27 @@ def c5_pedigree(n_lineages: int = 8, depth: int = 125, every: int = 5) -> tuple[
     gens = t.pair_rows(sampled)
     d = draw_observations(gens, TRUE_PARAMS, TRUE_P0UU, _rng(5))
     return np.concatenate([gens, d[:, None]], axis=1), TRUE_P0UU
+
+
+def _model_divergence_by_triple(gens: np.ndarray, p_uu: float, alpha: float, beta: float, weight: float) -> np.ndarray:
+    """model_divergence evaluated once per distinct (t0, t1, t2) row (deep pedigrees: 20 100 rows, 950 distinct)"""
+    uniq, inv = np.unique(gens.astype(np.int64), axis=0, return_inverse=True)
+    return model_divergence(uniq.astype(np.float64), p_uu, alpha, beta, weight)[inv.reshape(-1)]
+
+
+def c5_windows(n_windows: int, window_offset: int = 0, every: int = 5):
+    """BASELINE C5: the deep pedigree (8 lineages x 125 generations, every 5th generation sampled: N = 20 100) with
+    window-specific rates, as c4_windows.  Window w's data depends only on its GLOBAL index.
+    Returns (generations N x 3, D [W x N], p0uu [W], true params [W x 4])."""
+    t, sampled = c5_tree(every=every)
+    gens = t.pair_rows(sampled)
+    D = np.empty((n_windows, gens.shape[0]))
+    p0 = np.empty(n_windows)
+    params = np.empty((n_windows, 4))
+    for w in range(n_windows):
+        rng = _rng(5000 + window_offset + w)
+        params[w] = TRUE_PARAMS * np.array([rng.uniform(0.5, 2.0), rng.uniform(0.5, 2.0), 1.0, 1.0])
+        p0[w] = rng.uniform(0.6, 0.9)
+        dt = _model_divergence_by_triple(gens, p0[w], *params[w, :3])
+        D[w] = np.maximum(params[w, 3] + dt + rng.normal(0.0, NOISE_SD, gens.shape[0]), 0.0)
+    return gens, D, p0, params

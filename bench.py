@@ -50,6 +50,28 @@ def make_workload(name: str, rank: int, world: int):
         return dict(gens=gens, D=D, p0=p0, S=10, B=1000, wr=25,
                     label="C4 shard: C3 topology, 25 windows x (10 starts + 1000 bootstraps) per GPU "
                           "(200 windows over 8 GPUs)")
+    if name == "c4s":
+        # BASELINE C4 as named: 200 windows in ALL, dealt to the GPUs in contiguous blocks -> strong scaling
+        from alphabeta_rs_amd.distributed import shard_range
+        w0, wn = shard_range(200, world, rank)
+        gens, D, p0, _ = synthetic.c4_windows(wn, window_offset=w0)
+        return dict(gens=gens, D=D, p0=p0, S=10, B=1000, wr=wn, w0=w0, scaling="strong",
+                    label="C4: C3 topology, 200 windows x (10 starts + 1000 bootstraps) in all, windows sharded over the "
+                          "GPUs (strong scaling)")
+    if name == "c5":
+        # BASELINE C5's per-GPU shard at its real size: 500 windows over 8 GPUs -> 63 windows per GPU
+        gens, D, p0, _ = synthetic.c5_windows(63, window_offset=63 * rank)
+        return dict(gens=gens, D=D, p0=p0, S=10, B=5000, wr=63,
+                    label="C5 per-GPU shard at full size: deep pedigree (N=20100 rows, T=125, K=950), 63 windows x "
+                          "(10 starts + 5000 bootstraps); rows streamed (materialised bootstrap observations, 8 B/row, "
+                          "re-read from HBM every evaluation; 25 GB of indices + 51 GB of observations resident)")
+    if name in ("ref1000_c3", "ref1000_g351"):
+        # the reference's DEFAULT shape: `alphabeta -i 1000` sets n_starts = n_boot = iterations = 1000
+        # (src/alphabeta.rs:33-54, src/arguments.rs:93-114), one pedigree
+        base = make_workload("c3" if name.endswith("c3") else "g351", rank, world)
+        base.update(S=1000, B=1000, label="reference default `-i 1000` (1000 starts + 1000 bootstraps, "
+                    "src/alphabeta.rs:33-54) on " + base["label"].split(",")[0])
+        return base
     if name == "mp":
         # the reference's default metaprofile shape (src/cli/metaprofile.rs:40-44 with -s 1: 3 regions x 100
         # windows; --iterations 100 -> 100 starts + 100 bootstraps per window), on the C3 topology
@@ -214,9 +236,17 @@ def quick_workload(A, ctx, name, seed, steps=3, **options):
     dt = (time.perf_counter() - t0) / steps
     cnt = plan.counters()
     kms = plan.kernel_ms()
+    kern = plan.last_kernels()
+    out = plan.download(allow_failed_windows=True)
     plan.close()
-    return {"workload": wl["label"], "fits_per_s": cnt["fits"] / dt, "ms_per_step": 1e3 * dt, "steps": steps,
-            "candidate_evals_per_s": (cnt["evals"] - cnt["evals_skipped"]) / dt, "kernel_ms": kms}
+    r = {"workload": wl["label"], "fits_per_s": cnt["fits"] / dt, "ms_per_step": 1e3 * dt, "steps": steps,
+         "candidate_evals_per_s": (cnt["evals"] - cnt["evals_skipped"]) / dt, "kernel_ms": kms,
+         "kernels": {k: f"{v[0]} ({v[1]} lanes per chain)" for k, v in kern.items()}}
+    if out["info_a"] is not None:   # starts that reached argmin's fixed point (ABN_FIT_MAX_ITERS after a rejected contraction)
+        r["starts_at_max_iters"] = int((out["info_a"]["status"] == 1).sum())
+        r["boots_at_max_iters"] = int((out["info_b"]["status"] == 1).sum())
+        r["evals_not_executed"] = {"starts": cnt["evals_skipped_starts"], "boot": cnt["evals_skipped_boot"]}
+    return r
 
 
 def pairwise_bench(A, ctx, shapes=((15, 4_000_000), (50, 2_000_000)), reps=5):
@@ -300,6 +330,46 @@ def stream_probe(A, ctx, seed, steps=2, every=5, B=8192, tag="C5 shard"):
                         "partly by the Infinity Cache, so only the large-working-set figure is a DRAM rate)"}
 
 
+def c5_full_shard(A, ctx, seed, steps=1):
+    """BASELINE C5's per-GPU shard at its real size (63 windows x (10 starts + 5000 bootstraps) x 20100 rows: 25 GB of
+    bootstrap indices and 51 GB of materialised observations resident in HBM), one warm-up pass and `steps` timed
+    passes; the roofline of its phase-B launch like stream_probe's."""
+    wl = make_workload("c5", 0, 1)
+    N, W, S, B = wl["gens"].shape[0], wl["wr"], wl["S"], wl["B"]
+    plan = A.Plan(ctx, wl["gens"], W, S, B, options=A.default_options(seed=seed))
+    dev_bytes = plan.device_bytes()
+    plan.set_windows(wl["D"], wl["p0"])
+    plan.run()
+    plan.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        plan.run()
+    plan.sync()
+    dt = (time.perf_counter() - t0) / steps
+    kms = plan.kernel_ms()
+    cnt = plan.counters()
+    kern = plan.last_kernels()
+    out = plan.download()
+    plan.close()
+    evals_b = int(out["info_b"]["evals"].sum()) - cnt["evals_skipped_boot"]
+    fits_b = W * B
+    ms = kms["fit_boot"]
+    alg = evals_b * (4 * N + 40) + fits_b * 112 + W * N * 16 + N * 2
+    streamed = evals_b * (8 * N + 40) + fits_b * (12 * N + 112)
+    sane = bool(np.isfinite(out["raw"]).all() and (out["best_start"] >= 0).all())
+    return {"workload": wl["label"], "fits_per_s": cnt["fits"] / dt, "ms_per_step": 1e3 * dt, "steps": steps,
+            "candidate_evals_per_s": (cnt["evals"] - cnt["evals_skipped"]) / dt, "kernel_ms": kms,
+            "kernels": {k: f"{v[0]} ({v[1]} lanes per chain)" for k, v in kern.items()},
+            "plan_device_bytes": dev_bytes, "all_rows_finite": sane,
+            "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": ms,
+                         "kernel": "abn_fit_kernel<64, stream> phase B (+ abn_make_dstar_kernel)",
+                         "algorithmic_bytes_per_launch": alg, "streamed_bytes_per_launch": streamed,
+                         "beyond_l2_GBps": streamed / (ms * 1e-3) / 1e9,
+                         "beyond_l2_frac_of_hbm_peak": streamed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "evaluations": evals_b}}
+
+
 def stream_sweep(A, ctx, seed):
     """The stream kernel with a co-resident working set far below and far above the 256 MiB Infinity Cache at a
     comparable number of co-resident wavefronts (the LDS scratch per chain decides how many fit): shorter / longer rows
@@ -351,12 +421,97 @@ def launch_ranks(args) -> int:
     return 0
 
 
+def single_process_main(args) -> None:
+    """`bench.py --single-process [--devices 0,1,..]`: the OTHER N > 1 form — one process, one host thread, a plan per
+    device, the bootstrap tables gathered by RCCL inside the library (abn_multi_*, csrc/abn_multi.hip; what the
+    `--devices` flag of the CLIs uses).  Same JSON contract; n_gpus = number of devices.  The job is the per-GPU
+    workload times the number of devices (weak scaling), or `c4s`'s fixed 200 windows (strong)."""
+    import alphabeta_rs_amd as A
+    from alphabeta_rs_amd import synthetic
+
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    n = len(devices)
+    if args.devices is None and args.gpus != n:
+        raise SystemExit("--gpus and --devices disagree")
+    A.load_library(build_if_missing=True)
+    if A.device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the ABneutral path has no CPU fallback")
+    seed = 20260101
+    strong = args.workload == "c4s"
+    if args.workload == "c3":                    # one window, the bootstraps sharded: 10000 per device
+        ped, p = synthetic.c3_pedigree()
+        gens, D, p0, S, B, W = ped[:, :3], ped[:, 3][None, :], np.array([p]), 10, 10000 * n, 1
+        label = f"C3 pedigree, 10 starts + {B} bootstraps (10000 per device; bootstraps sharded)"
+    elif args.workload in ("c4", "c4s"):
+        W = 200 if strong else 25 * n
+        gens, D, p0, _ = synthetic.c4_windows(W)
+        S, B = 10, 1000
+        label = f"C4: C3 topology, {W} windows x (10 starts + 1000 bootstraps), windows sharded over the devices"
+    else:
+        raise SystemExit("--single-process times the workloads c3, c4 and c4s")
+    opts = A.default_options(seed=seed, lanes_per_chain=args.lanes, strict_order=1 if args.strict_order else 0,
+                             no_fixed_point_skip=1 if args.execute_stuck_fits else 0)
+    m = A.MultiPlan(devices, gens, W, S, B, options=opts)
+    m.set_windows(D, p0)
+    for _ in range(args.warmup):
+        m.run()
+    m.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m.run()
+    m.sync()
+    elapsed = time.perf_counter() - t0
+    cnt = m.counters()
+    kms = [m.kernel_ms(i) for i in range(n)]
+    out = m.download()
+    N = gens.shape[0]
+    # sanity at full size: every row finite; the table does not depend on how it was sharded (tests/test_gpu_multi.py
+    # compares it with a plain plan byte for byte)
+    sane = bool(np.isfinite(out["raw"]).all())
+    sh = m.shard(0)
+    fits_b0 = sh["n_windows"] * sh["n_boot"]
+    kern_s = max(k["fit_boot"] for k in kms) * 1e-3
+    alg0 = fits_b0 * (4 * N + 5 * 32 + 40) + sh["n_windows"] * N * 19
+    dt = elapsed / args.steps
+    # phase A is repeated on every device when the bootstraps are sharded: count those fits once
+    reps = (n - 1) * W * S if W < n else 0
+    ev_a = int(out["info_a"]["evals"].sum()) if reps else 0
+    fits = cnt["fits"] - reps
+    evals = cnt["evals"] - cnt["evals_skipped"] - (n - 1) * ev_a
+    result = {
+        "metric": "ABneutral model fits/sec (pedigree x bootstraps x windows)", "value": fits / dt, "unit": "fits/s",
+        "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": label, "rows": N, "windows": W, "starts": S, "bootstraps": B, "devices": devices,
+                   "parallelism": "abn_multi_* (one process): a plan per device from one host thread, RCCL "
+                                  "all-gather / broadcast of the bootstrap tables inside the library"
+                                  + (" (forced on one device: ABN_MULTI_FORCE_RCCL)" if os.environ.get("ABN_MULTI_FORCE_RCCL") else "")},
+        "candidate_evals_per_s": evals / dt, "fits_per_step": fits, "evals_per_step": evals,
+        "kernel_ms_per_device": kms, "all_rows_finite": sane,
+        "roofline": {"bound": "hbm", "achieved": alg0 / kern_s / 1e9 if kern_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": (alg0 / kern_s / 1e9 if kern_s > 0 else 0.0) / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "phase-B fit kernel of device 0's shard (slowest device's HIP-event time)",
+                     "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg0,
+                     "note": "LDS-resident fits: nominal HBM roofline, see the process-per-GPU line for valu_issue"},
+    }
+    m.close()
+    print(json.dumps(result), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "g351", "c5s", "mp", "pw"])
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default 200 for the millisecond workloads — long enough for a 5 s GPU-busy "
+                         "sampler to see the run —, 20 for g351 / mp, 5 for c5s, 1 for the 6 s steps of c5)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c4s", "g351", "c5s", "c5", "mp", "pw",
+                                                         "ref1000_c3", "ref1000_g351"])
+    ap.add_argument("--single-process", action="store_true",
+                    help="time abn_multi_* — ONE process driving the devices of --devices, RCCL gather inside the library "
+                         "— instead of one process per GPU; n_gpus = number of devices")
+    ap.add_argument("--devices", default=None, help="device ordinals for --single-process, e.g. 0,1,2,3 (default 0..gpus-1)")
+    ap.add_argument("--no-c5-full", action="store_true", help="skip the full-size C5 shard (76 GB, ~20 s) of the default line")
     ap.add_argument("--lanes", type=int, default=0, help="lanes of a wavefront per chain (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--execute-stuck-fits", action="store_true",
@@ -379,6 +534,12 @@ def main():
                     help="also run the stream-mode kernel with a co-resident working set far below / far above the "
                          "256 MiB Infinity Cache (slow to set up: a 123k-row pedigree)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"c5": 1, "c5s": 5, "g351": 20, "mp": 20, "pw": 20, "ref1000_c3": 20, "ref1000_g351": 20}.get(args.workload, 200)
+    if args.warmup is None:
+        args.warmup = 1 if args.workload == "c5" else 3
+    if args.single_process:
+        return single_process_main(args)
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -443,11 +604,14 @@ def main():
     opts = A.default_options(seed=seed, lanes_per_chain=args.lanes, strict_order=1 if args.strict_order else 0,
                              no_fixed_point_skip=1 if args.execute_stuck_fits else 0)
     by_boot = wl.get("shard") == "bootstraps"
-    plan = A.Plan(ctx, wl["gens"], Wr, S, B, window_offset=0 if by_boot else rank * Wr,
+    plan = A.Plan(ctx, wl["gens"], Wr, S, B, window_offset=0 if by_boot else wl.get("w0", rank * Wr),
                   boot_offset=rank * B if by_boot else 0, options=opts)
     # the bootstrap table lives in a torch tensor so that RCCL can gather it without a copy
     raw_local = torch.empty((Wr, B, 7), dtype=torch.float64, device="cuda")
     plan.bind_raw(raw_local.data_ptr())
+    strong = wl.get("scaling") == "strong"
+    if strong and collective and 200 % world:
+        raise SystemExit("c4s: the in-place all-gather needs equal blocks: 200 windows must divide by the GPU count")
     raw_all = torch.empty((world * Wr, B, 7), dtype=torch.float64, device="cuda") if collective else raw_local
     plan.set_windows(wl["D"], wl["p0"])          # H2D + index-buffer generation: outside the timed region
 
@@ -529,7 +693,9 @@ def main():
             alg_bytes = evals_b * (4 * N + 40) + fits_b * 112 + Wr * N * 16 + N * 2 + K * 4 + Wr * 56
             streamed_bytes = evals_b * (8 * N + 40) + fits_b * (12 * N + 112)  # tid (2 B/row) is L2-resident
         else:
-            alg_bytes = fits_b * (4 * N + 56 + 32 + 24) + Wr * N * 16 + N * 2 + K * 4 + Wr * 56
+            # 4N (index row) + 5 x 32 (start simplex) + 40 (candidate in, cost out) per LDS-resident fit,
+            # shared bytes N (3 + 8 + 8) per window counted once per launch
+            alg_bytes = fits_b * (4 * N + 5 * 32 + 40) + Wr * N * 19
         kern_s = kms["fit_boot"] * 1e-3
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         flops_eval = 45 * T + 53 * K + 4 * N + 60
@@ -565,9 +731,11 @@ def main():
         result = {
             "metric": "ABneutral model fits/sec (pedigree x bootstraps x windows)",
             "value": fits_per_s, "unit": "fits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl["label"], "rows": N, "windows_per_gpu": Wr, "starts": S, "bootstraps": B,
+                       "plan_device_bytes": plan.device_bytes(), "kernels": plan.last_kernels(),
                        "reduction_tree": hex(tree_code), "parallelism": f"{'bootstraps' if by_boot else 'windows'} sharded over {world} GPU(s), "
                                                                  "one RCCL all-gather of the bootstrap tables"},
             "candidate_evals_per_s": evals_per_s,
@@ -585,8 +753,10 @@ def main():
         if world == 1 and not args.no_extras:
             if Wr == 1:
                 result["pcie_inclusive"] = pcie_inclusive(A, ctx, wl, opts)
-            result["extra_workloads"] = {n: quick_workload(A, ctx, n, seed) for n in ("c2", "c4", "g351")
-                                         if n != args.workload}
+            result["extra_workloads"] = {n: quick_workload(A, ctx, n, seed)
+                                         for n in ("c2", "c4", "g351", "ref1000_c3", "ref1000_g351") if n != args.workload}
+            if not args.no_c5_full and args.workload != "c5":
+                result["extra_workloads"]["c5_full_shard"] = c5_full_shard(A, ctx, seed)
             if not args.strict_order:   # what the reference's summation order costs on this workload
                 so = quick_workload(A, ctx, args.workload, seed, strict_order=1)
                 so["price"] = fits_per_s / so["fits_per_s"]

@@ -58,7 +58,9 @@ typedef struct abn_options {
                                            number of fits in the launch — so results are independent of batch size
                                            and of how a job is sharded over GPUs; few-chain launches use one (or
                                            four) wavefronts per chain and reproduce the same tree bit for bit     */
-  int32_t strict_order;                 /* abn_cost_batch: 1 = serial row-order sum (reference order)  */
+  int32_t strict_order;                 /* 1 = every cost sums its residuals serially in row order, the reference's
+                                           `square_sum += ...` (src/structs.rs:206-213): cost AND fit entry points,
+                                           bit-equal to the oracle's lanes = 1; abn_fit_info.lanes reports 1     */
   int32_t shrink_on_failed_contraction; /* 0 = argmin 0.8.1 behaviour; 1 = textbook Nelder-Mead        */
   int32_t max_iters_start;              /* 10000, src/ab_neutral.rs:62                                 */
   int32_t max_iters_boot;               /* 1000,  src/boot_model.rs:81                                 */
@@ -232,6 +234,15 @@ int abn_plan_failed_windows(abn_plan* plan, int32_t* n_failed);
 int abn_plan_counters(abn_plan* plan, int64_t* out5);
 /* number of bytes of device memory the plan holds (index buffer included) */
 int abn_plan_device_bytes(abn_plan* plan, int64_t* bytes);
+/* which fit kernel the last run of each phase used (the choice depends on the size of the launch, never the bits):
+ * out[0] = kernel of phase A (ABN_KERNEL_*), out[1] = its lanes per chain, out[2] / out[3] the same for phase B */
+#define ABN_KERNEL_NONE 0         /* the phase has not run                                                   */
+#define ABN_KERNEL_SPECULATIVE 1  /* four wavefronts per chain (few chains: latency-bound)                   */
+#define ABN_KERNEL_RESIDENT 2     /* one launch, pedigree in LDS; lanes = 64: a wavefront per chain          */
+#define ABN_KERNEL_PERSISTENT 3   /* resident, persistent wavefronts with a chain queue and time slicing     */
+#define ABN_KERNEL_STREAM 4       /* rows re-read from HBM every evaluation                                  */
+#define ABN_KERNEL_TWO_PASS 5     /* resident, long chains parked and resumed in a second launch             */
+int abn_plan_last_kernels(abn_plan* plan, int32_t* out4);
 
 /* ------------------------------------------------------------------ (5) one process, several GPUs of a node
  * The metaprofile loop (src/cli/metaprofile.rs:50-72) over all MI355X of a node from ONE host thread: a plan per
@@ -265,6 +276,8 @@ int abn_multi_shard(abn_multi* m, int32_t device_index, int32_t* out4);
  * `device_index` of `n_devices` takes (contiguous balanced blocks of windows; with fewer windows than devices every
  * device takes all windows and a block of the bootstraps) — the rule of the one-process-per-GPU path too */
 int abn_multi_plan_shard(int32_t n_windows, int32_t n_boot, int32_t n_devices, int32_t device_index, int32_t* out4);
+/* HIP-event milliseconds of devices[device_index]'s last run: ms3 = (phase A, selection, phase B), as abn_plan_kernel_ms */
+int abn_multi_kernel_ms(abn_multi* m, int32_t device_index, double* ms3);
 /* the gathered table raw[W x B x 7] in the memory of devices[device_index] (valid after abn_multi_sync) */
 int abn_multi_raw_device_ptr(abn_multi* m, int32_t device_index, void** dev_ptr);
 /* as abn_plan_download for all W windows (raw comes from the first device's gathered table); returns
