@@ -1166,7 +1166,6 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
   int fin_status = 2;
   int q_start = 0;           // time slicing: evals of this chain when its current quantum began
   bool fresh_done = false;   // this group has seen the queue of unstarted chains empty
-  unsigned n_written = 0;    // fits this group has finished (results written): summed into slice_status[1] at the end
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     vx[k] = 0.0;
@@ -1482,9 +1481,9 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
           sd(31, __longlong_as_double(have_best ? 1ll : 0ll));
         }
       } else if (fin) {
-        n_written += 1u;
         if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
         if (gl == 0) {
+          if (a.slice_status) atomicAdd(a.slice_status + 1, 1u);  // fits finished (no return value: nobody waits for it)
           FitInfoDev fo;
           fo.best_cost = best_cost;
           fo.iters = iter;
@@ -1564,13 +1563,6 @@ __global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs 
       }
       __syncthreads();
     }
-  }
-  // fits finished by this wavefront (n_written is replicated in a group: its leader's copy counts)
-  if (a.slice_status) {
-    unsigned mine = gl == 0 ? n_written : 0u;
-#pragma unroll
-    for (int off = G; off < kWave; off <<= 1) mine += (unsigned)__shfl_xor((int)mine, off, kWave);
-    if (lane == 0 && mine) atomicAdd(a.slice_status + 1, mine);
   }
 }
 
