@@ -217,6 +217,14 @@ constexpr size_t kLdsResidentMax = 40 * 1024;
 #define ABN_PERSIST_WAVES 3072
 #endif
 constexpr long long kPersistWaves = ABN_PERSIST_WAVES;  // wavefronts of a persistent launch: 3 per SIMD x 4 SIMDs x 256 CUs
+// A launch that would just about fill the resident wavefronts (2048 < wavefronts <= 3072: C3's 10 000 bootstraps are 2500)
+// runs persistent on 2048 of them instead: the last fifth of the chains waits in the queue, finished groups refill and
+// time slicing evens out the tail (C3 phase B 2.61 -> 2.53 ms; 1792 / 2304 wavefronts: 2.71 / 2.82 ms; round 3)
+#ifndef ABN_PERSIST_WAVES_SMALL
+#define ABN_PERSIST_WAVES_SMALL 2048
+#endif
+constexpr long long kPersistWavesSmall = ABN_PERSIST_WAVES_SMALL;
+static long long persist_waves_for(long long blocks) { return blocks > kPersistWaves ? kPersistWaves : kPersistWavesSmall; }
 #ifndef ABN_PHASE_A_SPEC_MAX
 #define ABN_PHASE_A_SPEC_MAX 1024
 #endif
@@ -348,8 +356,8 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, int* kin
   // More wavefronts than the GPU holds at once and several chains per wavefront: the persistent kernel, whose
   // groups take the next chain from a queue when their fit ends (abn_fit_refill_kernel)
   const bool refill = a.queue != nullptr && rmax > 0 && ng > 1 && a.iter_cap == 0 && a.resume == 0 &&
-                      blocks > kPersistWaves;
-  if (refill) blocks = kPersistWaves;
+                      blocks > kPersistWavesSmall;
+  if (refill) blocks = persist_waves_for(blocks);
   if (!refill) a.quantum = 0;
   // Helper groups (FitArgs::helpers): packed resident launches.  A launch that does not fill the resident wavefronts is
   // dealt over all of them (FitArgs::spread), so that some groups are helpers from the first step on.
@@ -959,7 +967,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   }
   {  // time slicing for launches that outgrow the resident set of the persistent kernel (4 x kPersistWaves chains at 16 lanes)
     const size_t chains = W * std::max(S, B);
-    if (kQuantum > 0 && p->lanes < kWave && chains > (size_t)kPersistWaves * (size_t)(kWave / p->lanes) &&
+    if (kQuantum > 0 && p->lanes < kWave && chains > (size_t)kPersistWavesSmall * (size_t)(kWave / p->lanes) &&
         chains * 32 * sizeof(double) <= kSliceStateMax && chains < (1u << 27) && p->opt.window_groups <= 1) {
       if (p->nm_state.n < chains * 32) PALLOC(nm_state, chains * 32);
       p->slice_cap = (unsigned)(chains * 16 / kParkShards + 4096);   // per shard; a full shard just stops parking
