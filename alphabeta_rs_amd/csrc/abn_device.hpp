@@ -1236,8 +1236,11 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
 // ------------------------------------------------------------------------------------------------
 constexpr int ST_IDLE = 13;
 
+#ifndef ABN_REFILL_MIN_WAVES
+#define ABN_REFILL_MIN_WAVES 3
+#endif
 template <int G, int RMAX>
-__global__ __launch_bounds__(kWave, 3) void abn_fit_refill_kernel(const FitArgs a) {
+__global__ __launch_bounds__(kWave, ABN_REFILL_MIN_WAVES) void abn_fit_refill_kernel(const FitArgs a) {
   static_assert(RMAX > 0, "resident mode only");
   constexpr int NG = kWave / G;
   constexpr int RR = RMAX;
