@@ -429,6 +429,10 @@ def single_process_main(args) -> None:
     import alphabeta_rs_amd as A
     from alphabeta_rs_amd import synthetic
 
+    # stdout carries exactly ONE line, the JSON: RCCL prints a version banner on file descriptor 1 when it is bound
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
     devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
     n = len(devices)
     if args.devices is None and args.gpus != n:
@@ -495,6 +499,8 @@ def single_process_main(args) -> None:
                      "note": "LDS-resident fits: nominal HBM roofline, see the process-per-GPU line for valu_issue"},
     }
     m.close()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
     print(json.dumps(result), flush=True)
 
 

@@ -2,7 +2,7 @@
 """Turns the rocprofv3 CSVs of one bench.py run (kernel trace + separate --pmc passes) into the small
 summaries committed under profiles/.  Usage (scripts/profile_round.sh does all of it on the GPU box):
   python profiles/summarize_rocprof.py gpurun_out/prof_c3 r01_c3 c3
-Splits the two launches of abn_fit_kernel per step by grid size (phase A = starts, phase B = bootstraps).
+Splits the fit launches of a step by kernel and grid size (phase A = starts, phase B = bootstraps: the largest grid).
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
 (MI355X_MICROARCH.md §HBM), so hbm_bytes_per_launch = 2*FETCH + WRITE is an upper-side estimate here
 (this kernel's loads are 4- and 8-byte per lane, an uncalibrated width)."""
@@ -17,14 +17,22 @@ from pathlib import Path
 src, tag, workload = Path(sys.argv[1]), sys.argv[2], sys.argv[3]
 out = Path(__file__).resolve().parent
 
-stats = glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv"))[0]
+import os
+
+
+def newest(pattern):   # gpurun merges every run's files into the same directories: take the latest
+    files = glob.glob(pattern)
+    return max(files, key=os.path.getmtime) if files else None
+
+
+stats = newest(str(src / "kt" / "*" / "*_kernel_stats.csv"))
 shutil.copy(stats, out / f"{tag}_kernel_stats.csv")
 
-trace = glob.glob(str(src / "kt" / "*" / "*_kernel_trace.csv"))[0]
+trace = newest(str(src / "kt" / "*" / "*_kernel_trace.csv"))
 dur = collections.defaultdict(list)
 for r in csv.DictReader(open(trace)):
     name = r["Kernel_Name"]
-    if "abn_fit_kernel" in name:
+    if "abn_fit_" in name:    # abn_fit_kernel / abn_fit_refill_kernel / abn_fit_spec_kernel
         name += f" grid={r['Grid_Size_X']}"
     dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 summary = {"workload": workload, "kernels": {}}
@@ -33,16 +41,16 @@ for k, v in dur.items():
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    files = glob.glob(str(src / d / "*" / "*_counter_collection.csv"))
-    if not files:
+    f = newest(str(src / d / "*" / "*_counter_collection.csv"))
+    if not f:
         continue
-    for r in csv.DictReader(open(files[0])):
+    for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        if "abn_fit_kernel" in name:
+        if "abn_fit_" in name:
             name += f" grid={r['Grid_Size']}"
         pmc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary["pmc_avg_per_launch"] = {k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in pmc.items()}
-big = [k for k in summary["pmc_avg_per_launch"] if "abn_fit_kernel" in k]
+big = [k for k in summary["pmc_avg_per_launch"] if "abn_fit_" in k]   # phase B = the launch with the largest grid
 if big:
     b = max(big, key=lambda k: int(k.split("grid=")[1]))
     p = summary["pmc_avg_per_launch"][b]

@@ -72,7 +72,7 @@ def test_bench_single_process_form(workload, force):
                         "--steps", "3", "--warmup", "1"], capture_output=True, text=True, cwd=str(ROOT), timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and len(r.stdout.strip().splitlines()) == 1     # RCCL's banner must not reach stdout
     j = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
