@@ -8,7 +8,7 @@ wavefronts runs a step of each in t(k) microseconds (measured: 1.87 / 2.6 / 3.0 
                running chain of the same wavefront in the same step as its reflection: an iteration whose second
                evaluation was speculated costs one step instead of two
 
-usage: sched_sim.py traces.npz   (tr[nb, max_iters] u8, iters[nb])
+usage: sched_sim.py traces.npz   (tr[nb, max_iters] u8, iters[nb]: written by tests/fuzz/gen_branch_traces.py)
 """
 import sys
 

@@ -35,7 +35,8 @@ def main(seconds=120, seed=0):
             s0 *= rng.uniform(-3, 50, s0.shape)           # wild starts: negative rates, huge weights
         if rng.random() < 0.1:
             s0[0, int(rng.integers(0, 5)), int(rng.integers(0, 4))] = np.nan
-        o = A.default_options(lanes_per_chain=lanes, shrink_on_failed_contraction=variant)
+        strict = int(rng.random() < 0.15)                 # serial row-order sums: info.lanes == 1, oracle lanes = 1
+        o = A.default_options(lanes_per_chain=lanes, shrink_on_failed_contraction=variant, strict_order=strict)
         eqp, ew = float(rng.uniform(0.3, 0.9)), float(rng.choice([0.0, 0.7, 1.0]))
         try:
             best, info = ctx.fit_batch(ped, p0, eqp, ew, s0, iters, options=o)

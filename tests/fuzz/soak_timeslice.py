@@ -19,7 +19,8 @@ def digest(out):
 def main(seconds=120):
     ctx = A.Context(0)
     t_end = time.time() + seconds
-    for name in ("c4", "mp"):
+    names = ("c3", "c4", "mp")     # c3: one window on 2048 persistent wavefronts (round 3)
+    for k, name in enumerate(names):
         wl = bench.make_workload(name, 0, 1)
         seed = 20260101
         plan = A.Plan(ctx, wl["gens"], wl["wr"], wl["S"], wl["B"], options=A.default_options(seed=seed))
@@ -36,7 +37,7 @@ def main(seconds=120):
             assert np.array_equal(out["raw"][w], raw, equal_nan=True), (name, w)
             assert np.array_equal(out["info_b"][w]["evals"], res["evals"]), (name, w)
         runs, t_note = 1, time.time()
-        while time.time() < t_end - (seconds / 2 if name == "c4" else 0):
+        while time.time() < t_end - seconds * (len(names) - 1 - k) / len(names):
             plan.run()
             d = digest(plan.download())
             runs += 1
