@@ -1,6 +1,6 @@
 // `alphabeta` command-line tool: same flags, console output and output files as the reference binary
 // (src/cli/alphabeta.rs:8-38, src/arguments.rs:93-152), running the ABneutral path on an MI355X through
-// libabneutral_hip.so.  Extra flags (not in the reference): --seed, --device, --lanes, and
+// libabneutral_hip.so.  Extra flags (not in the reference): --seed, --device(s), --lanes, --strict-order, and
 // --pedigree FILE --p0uu X to start from an existing pedigree file instead of nodelist/edgelist.
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +25,8 @@ static void usage() {
       "      --device <N>               HIP device ordinal [default: 0]\n"
       "      --devices <A,B,..>         several HIP devices: the bootstraps are sharded over them, tables gathered with RCCL\n"
       "      --lanes <G>                lanes of a wavefront per Nelder-Mead chain: 0 (auto), 8, 16, 32, 64\n"
+      "      --strict-order             sum every cost's residuals serially in row order, exactly as the reference does\n"
+      "                                 (src/structs.rs:206-213): bit-equal to a reference-order CPU run, ~1.7x the time\n"
       "      --pedigree <FILE>          use this pedigree file (src/pedigree.rs:62-79 format) instead of building one\n"
       "      --p0uu <X>                 proportion of unmethylated sites at G0 (required with --pedigree)\n"
       "  -h, --help                     Print help\n"
@@ -38,6 +40,7 @@ int main(int argc, char** argv) {
   double p0uu_given = -1.0;
   uint64_t seed = 20260101ull;
   int device = 0, lanes = 0;
+  bool strict_order = false;
   std::string devices_arg;
   auto need = [&](int& i) -> const char* {
     if (i + 1 >= argc) {
@@ -64,6 +67,7 @@ int main(int argc, char** argv) {
     else if (a == "--device") device = std::atoi(val().c_str());
     else if (a == "--devices") devices_arg = val();
     else if (a == "--lanes") lanes = std::atoi(val().c_str());
+    else if (a == "--strict-order") strict_order = true;
     else if (a == "--pedigree") ped_file = val();
     else if (a == "--p0uu") p0uu_given = std::strtod(val().c_str(), nullptr);
     else if (a == "-h" || a == "--help") { usage(); return 0; }
@@ -103,6 +107,7 @@ int main(int argc, char** argv) {
     if (device_list().empty()) device_list().push_back(device);
     dev.options.seed = seed;
     dev.options.lanes_per_chain = lanes;
+    dev.options.strict_order = strict_order ? 1 : 0;
     RunResult r;
     if (!ped_file.empty()) {
       if (!(p0uu_given > 0.0 && p0uu_given < 1.0)) {

@@ -363,6 +363,15 @@ def test_alphabeta_cli_end_to_end(abn, gpu_ctx, golden, oracle, tmp_path):
     assert r2.returncode == 0, r2.stdout + r2.stderr
     assert np.array_equal(np.load(multi / "raw.npy"), raw)
     assert (multi / "analysis.txt").read_text() == (tmp_path / "analysis.txt").read_text()
+    # --strict-order: the reference's serial summation order end to end (bit-equal to the oracle's lanes = 1)
+    strict = tmp_path / "strict"
+    strict.mkdir()
+    r3 = subprocess.run([cli, "-i", str(iters), "-n", "./data/nodelist.txt", "-e", "./data/edgelist.txt", "-o", str(strict),
+                         "--seed", str(seed), "--strict-order"], capture_output=True, text=True, cwd=str(gold))
+    assert r3.returncode == 0, r3.stdout + r3.stderr
+    k1, model1, pred1, resid1, _, _ = _oracle_ab_neutral(oracle, abn, ped, p0, p0, 1.0, iters, seed, 1)
+    sraw, _ = oracle.boot_model(ped, model1, pred1, resid1, p0, p0, 1.0, seed, 0, 0, iters, lanes=1)
+    assert np.array_equal(np.load(strict / "raw.npy"), sraw)
     # the reference's bootstrap.png (src/boot_model.rs:105-109) from the file the CLI wrote
     import sys
     pr = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "scripts" / "plot_bootstrap.py"),
