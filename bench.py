@@ -655,11 +655,13 @@ def main():
         # the gathered table must hold every rank's shard: compare per-rank checksums
         step()
         fence()
-        mine = raw_local.sum().reshape(1)
-        sums = torch.empty(world, dtype=torch.float64, device="cuda")
+        # checksums over the BIT PATTERNS (int64 sums wrap: exact and independent of the order of summation; a sum of
+        # the doubles differs in the last bits between two reduction kernels once the shards are large)
+        mine = raw_local.view(torch.int64).sum().reshape(1)
+        sums = torch.empty(world, dtype=torch.int64, device="cuda")
         dist.all_gather_into_tensor(sums, mine)
-        got = raw_all.view(world, -1).sum(dim=1)
-        if not torch.equal(got, sums):
+        got = raw_all.view(world, -1).view(torch.int64).sum(dim=1)
+        if not torch.equal(got, sums) or not torch.equal(raw_all[rank * Wr:(rank + 1) * Wr], raw_local):
             raise SystemExit(f"rank {rank}: gathered bootstrap table does not match the shards")
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

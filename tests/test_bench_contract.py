@@ -58,6 +58,14 @@ def test_bench_spawns_its_own_ranks():
     assert len(lines) == 1 and len(r.stdout.strip().splitlines()) == 1
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["fits_per_step"] == 10 + 2 * 10000    # phase A counted once, bootstraps sharded
+    # BASELINE C4 as strong scaling: 200 windows in all, 100 per rank, the gathered table checked against the shards
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--backend", "gloo", "--workload", "c4s",
+                        "--steps", "2", "--warmup", "1", "--no-stream-probe", "--no-cpu-baseline", "--no-extras"],
+                       capture_output=True, text=True, cwd=str(ROOT), timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["fits_per_step"] == 200 * 1010
+    assert j["config"]["windows_per_gpu"] == 100
 
 
 @pytest.mark.gpu

@@ -853,3 +853,54 @@ def test_reference_unit_tests_through_the_cpp_mirror(abn, gpu_ctx):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "same_as_r ... ok" in r.stdout and "test_cost_function ... ok" in r.stdout
     assert "build_pedigree ... ok" in r.stdout
+
+
+def test_kernel_choice_follows_the_launch_size(abn, gpu_ctx):
+    """abn_plan_last_kernels: which fit kernel a launch of a given size gets.  The choice never changes a
+    bit of the result (test_results_do_not_depend_on_launch_size); this pins the rules themselves on the C3 topology."""
+    from alphabeta_rs_amd import synthetic
+
+    ped, p0 = synthetic.c3_pedigree()
+    deep, dp0 = synthetic.c5_pedigree(every=12)
+
+    def kernels(gens, d, p, W, S, B, **opts):
+        o = abn.default_options(max_iters_start=30, max_iters_boot=20, **opts)
+        plan = abn.Plan(gpu_ctx, gens, W, S, B, options=o)
+        plan.set_windows(np.tile(d, (W, 1)), np.full(W, p))
+        plan.run()
+        plan.download()
+        k = plan.last_kernels()
+        plan.close()
+        return k
+
+    k = kernels(ped[:, :3], ped[:, 3], p0, 1, 10, 10000)        # BASELINE C3: 2500 wavefronts of four chains
+    assert k["starts"] == ("speculative", 64) and k["boot"] == ("persistent", 16)
+    k = kernels(ped[:, :3], ped[:, 3], p0, 1, 10, 1000)         # few bootstraps: latency-bound like the starts
+    assert k["boot"] == ("speculative", 64)
+    k = kernels(ped[:, :3], ped[:, 3], p0, 1, 10, 2500)         # a wavefront per chain still beats packing
+    assert k["boot"] == ("resident", 64)
+    k = kernels(ped[:, :3], ped[:, 3], p0, 1, 10, 6000)         # packed, fits the GPU: the plain launch
+    assert k["boot"] == ("resident", 16)
+    k = kernels(ped[:, :3], ped[:, 3], p0, 25, 10, 1000)        # a multi-window shard: persistent with time slicing
+    assert k["starts"] == ("speculative", 64) and k["boot"] == ("persistent", 16)
+    k = kernels(ped[:, :3], ped[:, 3], p0, 1, 10, 10000, strict_order=1)   # strict order: plain launches only
+    assert k["starts"] == ("resident", 64) and k["boot"] == ("resident", 16)
+    k = kernels(deep[:, :3], deep[:, 3], dp0, 1, 2, 4)          # 3240 rows: streamed
+    assert k["starts"][0] == "stream" and k["boot"][0] == "stream"
+
+
+def test_plan_may_outlive_its_context(abn):
+    """a plan destroyed after abn_shutdown (easy from Python: ctx.close() before the Plan is collected) used
+    to give its buffers back to a freed pool.  The pool is shared and closed now: the buffers are simply freed."""
+    from alphabeta_rs_amd import synthetic
+
+    ped, p0 = synthetic.c3_pedigree()
+    for _ in range(3):
+        ctx = abn.Context(0)
+        plan = abn.Plan(ctx, ped[:, :3], 2, 3, 8, options=abn.default_options(max_iters_start=20, max_iters_boot=10))
+        plan.set_windows(np.tile(ped[:, 3], (2, 1)), np.full(2, p0))
+        plan.run()
+        out = plan.download()
+        ctx.close()                    # abn_shutdown first ...
+        plan.close()                   # ... then abn_plan_destroy
+        assert np.isfinite(out["raw"]).all()
