@@ -8,8 +8,9 @@ ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 lib = ROOT / "gpurun_out" / "libabneutral_hip_stamps.so"
 lib.parent.mkdir(exist_ok=True)
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                "-DABN_STAMPS", "-o", str(lib), str(ROOT / "alphabeta_rs_amd/csrc/abn_api.hip")], check=True)
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-ldl",
+                "-DABN_STAMPS", "-DABN_MEASUREMENT_KNOBS", "-o", str(lib), str(ROOT / "alphabeta_rs_amd/csrc/abn_api.hip"),
+                str(ROOT / "alphabeta_rs_amd/csrc/abn_multi.hip")], check=True)
 import alphabeta_rs_amd as A
 A.LIB_PATH = lib
 A._lib = None
