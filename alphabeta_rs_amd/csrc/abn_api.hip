@@ -359,19 +359,6 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, int* kin
                       blocks > kPersistWavesSmall;
   if (refill) blocks = persist_waves_for(blocks);
   if (!refill) a.quantum = 0;
-  // Helper groups (FitArgs::helpers): packed resident launches.  A launch that does not fill the resident wavefronts is
-  // dealt over all of them (FitArgs::spread), so that some groups are helpers from the first step on.
-  a.helpers = 1;
-  a.spread = 0;
-#ifdef ABN_MEASUREMENT_KNOBS  // ABN_HELPERS=0: idle groups idle; ABN_SPREAD=1: chains dealt over all resident wavefronts
-  if (const char* e = getenv("ABN_HELPERS")) a.helpers = atoi(e);
-  if (const char* e = getenv("ABN_SPREAD"))
-    if (atoi(e) != 0 && kHelperGroups && !refill && rmax > 0 && ng > 1 && !a.strict && a.iter_cap == 0 && a.resume == 0 &&
-        blocks < kPersistWaves && chains > kPersistWaves) {
-      blocks = kPersistWaves;   // measured on C3: 2.75 -> 2.84 ms (every SIMD then holds three wavefronts): not the default
-      a.spread = (int)blocks;
-    }
-#endif
   if (refill && a.slice_status) HIPCHK(c, hipMemsetAsync(a.slice_status, 0, 2 * sizeof(unsigned), st));
   if (kind)
     *kind = refill ? ABN_KERNEL_PERSISTENT

@@ -100,14 +100,6 @@ struct FitArgs {
   //     lane, xor-butterfly 1, 2, 4, ... (group_sum_dpp).
   int tree;
   int strict;            // host dispatch only: the STRICT instantiation (serial row-order sum; `tree` is then 1)
-  // Helper groups (abn_fit_kernel with several chains per wavefront, resident): a lane group whose chain has finished —
-  // or that never had one — evaluates the expansion or contraction point of a running chain of its wavefront in the
-  // same step as that chain's reflection, so an iteration that needs a second evaluation costs one step instead of two.
-  //   helpers  0: off (every group idles when its chain is done: the round-2 behaviour; measurement aid)
-  //   spread   > 0: the chains are dealt over `spread` wavefronts — chain = group * spread + workgroup — so that a launch
-  //            that does not fill the resident wavefronts leaves helper groups from the first step on
-  int helpers;
-  int spread;
   // chains: W windows x C chains
   int W, C;
   int max_iters;
@@ -336,31 +328,6 @@ __device__ __forceinline__ double lane_fetch(double v, int src_lane) {  // ds_bp
   const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
   return __hiloint2double(hi, lo);
 }
-
-__device__ __forceinline__ double lane_fetch_addr(double v, int byte_addr) {  // ds_bpermute: v of lane byte_addr / 4
-  const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, __double2loint(v));
-  const int hi = __builtin_amdgcn_ds_bpermute(byte_addr, __double2hiint(v));
-  return __hiloint2double(hi, lo);
-}
-// index of the n-th set bit of m (bits 0 .. NB-1; 0 when there is none): m is wavefront-uniform, n per lane
-template <int NB>
-__device__ __forceinline__ int nth_set_bit(unsigned m, int n) {
-  int r = 0, cnt = 0;
-#pragma unroll
-  for (int k = 0; k < NB; ++k) {
-    const bool b = ((m >> k) & 1u) != 0u;
-    r = (b && cnt == n) ? k : r;
-    cnt += b ? 1 : 0;
-  }
-  return r;
-}
-
-// Build switch: -DABN_HELPER_GROUPS compiles the helper groups into abn_fit_kernel (measured, not shipped: see there)
-#ifdef ABN_HELPER_GROUPS
-constexpr bool kHelperGroups = true;
-#else
-constexpr bool kHelperGroups = false;
-#endif
 
 // Build switch: -DABN_NO_MATRIX_FMA compiles the VALU form (build_power_table) instead — same bits, for A/B timing.
 #ifdef ABN_NO_MATRIX_FMA
@@ -653,9 +620,8 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
   const int g = lane / G;
   const int gl = lane - g * G;
   const int dim = gl & 3;
-  constexpr bool HELP = kHelperGroups && (NG > 1) && !STREAM && !TWOPASS && !STRICT;  // helper groups (FitArgs::helpers)
   const long long total = (long long)a.W * a.C;
-  const long long slot = (HELP && a.spread > 0) ? (long long)g * a.spread + blockIdx.x : (long long)blockIdx.x * NG + g;
+  const long long slot = (long long)blockIdx.x * NG + g;
   long long chain_raw = slot;
   bool valid = slot < total;
   if constexpr (TWOPASS) {
@@ -736,24 +702,15 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
 #endif
   // ---- one cost evaluation; xd = this lane's dimension of its group's candidate.  Lanes of a quad hold
   // dimensions 0..3 of the same chain, so the candidate is re-assembled with four quad broadcasts.
-  // whose window constants and observations this group's evaluation reads: its own chain's, or (helper groups) those
-  // of the chain it evaluates a candidate for
-  const double* wc_h = wconst;
-  const double* dobs_h = dobs;
-  // `helper_c` (std::true_type: the helper-group loop below): the window constants and observations are read through
-  // wc_h / dobs_h, which a helper group points at the chain it works for
-  auto eval = [&](double xd, auto helper_c) -> double {
-    constexpr bool EH = decltype(helper_c)::value;
-    const double* wc_e = EH ? wc_h : wconst;
-    const double* dobs_e = EH ? dobs_h : dobs;
+  auto eval = [&](double xd) -> double {
     ABN_STAMP(6);  // Nelder-Mead bookkeeping since the previous evaluation
     const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
     const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
-    const double p_mm = wc_e[1];
-    const double sv0 = wc_e[0], sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;  // src/divergence.rs:44
+    const double p_mm = wconst[1];
+    const double sv0 = wconst[0], sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;  // src/divergence.rs:44
     const double puu = p_uu_est(al, be);                     // src/divergence.rs:92 (early: overlaps P2)
-    const double dq = puu - wc_e[2];
-    const double pen = wc_e[3] * (dq * dq);                  // src/structs.rs:210-212
+    const double dq = puu - wconst[2];
+    const double pen = wconst[3] * (dq * dq);                // src/structs.rs:210-212
     ABN_STAMP(0);
     // this lane's first triple is fetched before the power table is built and every later one a round ahead:
     // the LDS latency of the triple list stays off the path
@@ -793,7 +750,7 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
 #pragma unroll
         for (int q = 0; q < RC; ++q) {                       // all LDS reads first, then the arithmetic;
           const int i = gl + G * (q0 + q);                   // rows past the end read row N-1 and add +0.0
-          dv[q] = dobs_e[i < N ? i : N - 1];
+          dv[q] = dobs[i < N ? i : N - 1];
           tv[q] = dtab[(tidp[(q0 + q) / 2] >> (16 * ((q0 + q) & 1))) & 0xffffu];
         }
 #pragma unroll
@@ -989,7 +946,7 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
     // of a wavefront start together.
 #pragma unroll 1
     for (int k = 0; k < 5; ++k) {
-      const double f = eval(vx[0], std::false_type{});
+      const double f = eval(vx[0]);
       const double tv = vx[0];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1029,107 +986,35 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
     st = ST_REFLECT;
   }
 
-  // Helper groups (HELP; FitArgs::helpers).  The reference's iteration evaluates the reflection and then, depending on
-  // its cost, the expansion OR the contraction point (71 % of C3's bootstrap iterations need that second evaluation).
-  // Both points are known before the first cost, so a group without a running chain evaluates one of them for a running
-  // chain of its wavefront — on that chain's observations and window constants (LDS pointers), with its own scratch,
-  // its own lanes and hence the same reduction tree: the same bits the chain itself would compute one step later.  The
-  // chain then takes both decisions of the iteration in that step.  Which point: the kind the chain's previous
-  // iteration needed (a contraction follows a contraction 3 times in 4); a second helper, if there is one, takes the
-  // other.  Which group: the j-th idle group serves the j-th reflecting chain, first helpers before second ones.
-  // Nothing the reference would not evaluate is ever counted or used.
-  // MEASURED AND NOT SHIPPED (round 3): bit-exact (all parity tests), a lone long chain with three helper
-  // groups finishes 27 % sooner (scripts/helper_probe.py), C3's phase B gains 5 % against the same build with the helpers
-  // switched off — but the step that carries the helper code is 7 % slower than the one without (165 instead of 151
-  // VGPRs, the selects of the merged decision), a net loss of 2 %; keeping a lean copy of the step for wavefronts whose
-  // groups are all busy cost more (spills).  Compiled only with -DABN_HELPER_GROUPS (scripts/helpers_ab.sh).
-  bool pc = true;  // this chain's last iteration went to the contraction (initial guess: early iterations contract)
-  auto step = [&](auto helper_c) {
-    constexpr bool H = decltype(helper_c)::value;
-    double xq = xc;                          // the point this group evaluates
-    bool have_h1 = false, have_h2 = false;   // (running chain) a first / second helper evaluates for it in this step
-    int h1_addr = 0, h2_addr = 0;            // byte addresses (ds_bpermute) of the helpers' lanes
-    const bool first_is_c = pc;              // kind of the first helper's point
-    if constexpr (H) {
-      wc_h = wconst;
-      dobs_h = dobs;
-      const unsigned long long idle_b = __ballot(st == ST_DONE), refl_b = __ballot(st == ST_REFLECT);
-      unsigned I = 0, R = 0;                 // one bit per group: idle, about to evaluate a reflection
-#pragma unroll
-      for (int k = 0; k < NG; ++k) {
-        I |= (unsigned)((idle_b >> (k * G)) & 1ull) << k;
-        R |= (unsigned)((refl_b >> (k * G)) & 1ull) << k;
-      }
-      const int nI = __builtin_popcount(I), nR = __builtin_popcount(R);
-      if (nR > 0 && nI > 0 && a.helpers != 0) {
-        const unsigned below = (1u << g) - 1u;
-        const double x_e_own = x0 + (xr - x0) * 2.0;        // expansion  x0 + (xr - x0) * gamma
-        const double x_c_own = x0 + (vx[4] - x0) * 0.5;     // contraction x0 + (xw - x0) * rho
-        const double x_first = pc ? x_c_own : x_e_own, x_second = pc ? x_e_own : x_c_own;
-        // helper side: the ji-th idle group serves reflecting chain ji (first point) or ji - nR (second point)
-        const int ji = __builtin_popcount(I & below);
-        const bool helping = ((I >> g) & 1u) != 0u && ji < 2 * nR;
-        const int second = ji >= nR ? 1 : 0;
-        const int t = nth_set_bit<NG>(R, helping ? ji - second * nR : 0);
-        const int src = (t * G + gl) << 2;
-        const double xf = lane_fetch_addr(x_first, src), xs = lane_fetch_addr(x_second, src);
-        if (helping) {
-          xq = second ? xs : xf;
-          wc_h = lds + (size_t)t * a.chain_stride + (wconst - pw);
-          dobs_h = wc_h + 4;
-        }
-        // running side: where this chain's helpers sit
-        const int jr = __builtin_popcount(R & below);
-        const bool is_r = ((R >> g) & 1u) != 0u;
-        have_h1 = is_r && jr < nI;
-        have_h2 = is_r && nR + jr < nI;
-        h1_addr = (nth_set_bit<NG>(I, have_h1 ? jr : 0) * G + gl) << 2;
-        h2_addr = (nth_set_bit<NG>(I, have_h2 ? nR + jr : 0) * G + gl) << 2;
-      }
-    }
-    const double f = eval(xq, helper_c);
-    double fh1 = 0.0, fh2 = 0.0;
-    if constexpr (H) {
-      if (__ballot(have_h1) != 0ull) {
-        fh1 = lane_fetch_addr(f, h1_addr);
-        fh2 = lane_fetch_addr(f, h2_addr);
-      }
-    }
-    // ---- decisions of NelderMead::next_iter as predicates (no divergent control flow on the hot path).  `he` / `hc`:
-    // this iteration's second evaluation (expansion / contraction) has been made by a helper group in this very step —
-    // its decision is taken at once, with the same comparisons the ST_EXPAND / ST_CONTRACT step would make
+  while (__ballot(st != ST_DONE) != 0ull) {
+    const double f = eval(xc);
+    // ---- decisions of NelderMead::next_iter as predicates (no divergent control flow on the hot path)
     const bool active = st != ST_DONE;
     const bool is_ref = st == ST_REFLECT, is_exp = st == ST_EXPAND, is_con = st == ST_CONTRACT;
     const bool acc_r = is_ref && (f < c[3]) && (f >= c[0]);      // reflection accepted
     const bool go_exp = is_ref && !acc_r && (f < c[0]);           // try expansion
     const bool go_con = is_ref && !acc_r && !go_exp && (f >= c[3]);  // contraction towards the worst
     const bool nan_ref = is_ref && !acc_r && !go_exp && !go_con;  // only reachable with a NaN cost
-    const bool he = H && go_exp && (first_is_c ? have_h2 : have_h1);
-    const bool hc = H && go_con && (first_is_c ? have_h1 : have_h2);
-    const double f2 = (hc == first_is_c) ? fh1 : fh2;             // the helper's cost (only read when he || hc)
-    const bool keep_r = (is_exp && !(f < fr)) || (he && !(f2 < f));  // expansion not better: keep the reflection
-    const bool acc_c = (is_con && (f < c[4])) || (hc && (f2 < c[4]));
-    const bool rej_c = (is_con || hc) && !acc_c;
-    const bool do_insert = acc_r || is_exp || he || acc_c;
+    const bool keep_r = is_exp && !(f < fr);                      // expansion not better: keep the reflection
+    const bool acc_c = is_con && (f < c[4]);
+    const bool rej_c = is_con && !acc_c;
+    const bool do_insert = acc_r || is_exp || acc_c;
     const bool start_shrink = nan_ref || (rej_c && a.shrink_variant != 0);
     const bool do_begin = do_insert || (rej_c && a.shrink_variant == 0);  // argmin 0.8.1: rejected contraction leaves the simplex
-    evals += (active ? 1 : 0) + ((he || hc) ? 1 : 0);
+    evals += active ? 1 : 0;
     if (rej_c && a.shrink_variant == 0 && a.no_skip == 0) {  // fixed point: finish the chain (FitArgs::no_skip)
       const int rest = a.max_iters - iter - 1;               // iterations that would repeat this one
       evals += 2 * rest;
       iter += rest;
       if (a.skipped && gl == 0 && rest > 0) atomicAdd(a.skipped, 2ull * (unsigned long long)rest);
     }
+    const double xi = keep_r ? xr : xc;
+    const double fi = keep_r ? fr : f;
+    fr = is_ref ? f : fr;
     const double x_e = x0 + (xr - x0) * 2.0;        // expansion  x0 + (xr - x0) * gamma
     const double x_c = x0 + (vx[4] - x0) * 0.5;     // contraction x0 + (xw - x0) * rho
-    // the point that enters the simplex and its cost: ST_EXPAND step (xc = x_e): the better of x_e / x_r; a helper made
-    // the expansion (xc = x_r): the same choice; contraction: x_c; accepted reflection: xc = x_r
-    const double xi = he ? (keep_r ? xc : x_e) : (hc ? x_c : (keep_r ? xr : xc));
-    const double fi = he ? (keep_r ? f : f2) : (hc ? f2 : (keep_r ? fr : f));
-    fr = is_ref ? f : fr;
-    xc = (go_exp && !he) ? x_e : ((go_con && !hc) ? x_c : xc);
-    st = (go_exp && !he) ? ST_EXPAND : ((go_con && !hc) ? ST_CONTRACT : st);
-    if constexpr (H) pc = go_con ? true : (is_ref ? false : pc);
+    xc = go_exp ? x_e : (go_con ? x_c : xc);
+    st = go_exp ? ST_EXPAND : (go_con ? ST_CONTRACT : st);
     if (do_insert) {
       c[4] = fi;
       vx[4] = xi;
@@ -1142,7 +1027,7 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
 #pragma unroll 1
       for (int k = 1; k < 5; ++k) {
         const double nv = vx[0] + (vx[1] - vx[0]) * 0.5;
-        const double fk = eval(start_shrink ? nv : xc, std::false_type{});
+        const double fk = eval(start_shrink ? nv : xc);
         if (start_shrink) {
           ++evals;
 #pragma unroll
@@ -1159,8 +1044,7 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
         begin_iteration(true);
       }
     }
-  };
-  while (__ballot(st != ST_DONE) != 0ull) step(std::integral_constant<bool, HELP>{});
+  }
 
 #ifdef ABN_STAMPS
   if (a.dbg && chain_raw == 0 && gl == 0) {

@@ -2,7 +2,7 @@
 """GPU box: one wavefront of the packed kernel (16 lanes per chain) with ONE long chain and three chains that converge at
 once (degenerate start simplices): how much faster does the long chain finish when the idle groups evaluate its
 expansion / contraction points?  Run with ABNEUTRAL_HIP_LIB=build/libabn_knobs.so (-DABN_MEASUREMENT_KNOBS
--DABN_HELPER_GROUPS, see scripts/helpers_ab.sh) and ABN_HELPERS=0 / 1.  Measured: 0.973 -> 0.690 ms."""
+-DABN_HELPER_GROUPS on the sources patched with scripts/attic/helper_groups_*_r03.patch, see scripts/helpers_ab.sh) and ABN_HELPERS=0 / 1.  Measured: 0.973 -> 0.690 ms."""
 import os, sys, time
 from pathlib import Path
 import numpy as np

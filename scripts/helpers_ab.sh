@@ -1,7 +1,8 @@
 #!/bin/bash
-# GPU box: helper groups (abn_device.hpp: abn_fit_kernel, `step`) compiled out (build/libabn_nohelp.so: the shipped code
-# with -DABN_MEASUREMENT_KNOBS), compiled in and switched off / on (build/libabn_knobs.so: -DABN_MEASUREMENT_KNOBS
-# -DABN_HELPER_GROUPS, ABN_HELPERS=0|1).  Cross-compile both before the call:
+# GPU box: helper groups (the round-3 experiment: scripts/attic/helper_groups_{device,api}_r03.patch, reverse diffs — apply
+# with `patch -R` to a scratch copy of csrc/) compiled out (build/libabn_nohelp.so: the shipped code with
+# -DABN_MEASUREMENT_KNOBS), compiled in and switched off / on (build/libabn_knobs.so: the patched copy with
+# -DABN_MEASUREMENT_KNOBS -DABN_HELPER_GROUPS, ABN_HELPERS=0|1).  Cross-compile both before the call:
 #   for v in "nohelp" "knobs -DABN_HELPER_GROUPS"; do set -- $v; hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off \
 #     -fno-fast-math -fPIC -shared -ldl -DABN_MEASUREMENT_KNOBS $2 -o build/libabn_$1.so alphabeta_rs_amd/csrc/abn_{api,multi}.hip; done
 #   bash scripts/helpers_ab.sh [workloads...]
