@@ -163,8 +163,9 @@ def test_hip_strict_order_plan_multi_window_and_stream(oracle, abn, gpu_ctx):
         assert np.array_equal(out["models"][w], ref["model"]) and np.array_equal(out["raw"][w], ref["raw"])
         assert np.array_equal(out["info_b"]["evals"][w], ref["res"]["evals"])
     deep, dp0 = synthetic.c5_pedigree(every=25)            # 820 rows: resident at 64 lanes; every=12 -> streamed
-    for ped in (deep, synthetic.c5_pedigree(every=12)[0]):
-        o = abn.default_options(seed=SEED, strict_order=1, max_iters_start=40, max_iters_boot=30)
+    streamed = synthetic.c5_pedigree(every=12)[0]          # (both stream variants: materialised observations, index rows)
+    for ped, sm in ((deep, 0), (streamed, 0), (streamed, 1)):
+        o = abn.default_options(seed=SEED, strict_order=1, max_iters_start=40, max_iters_boot=30, stream_mode=sm)
         plan = abn.Plan(gpu_ctx, ped[:, :3], 1, 3, 5, options=o)
         plan.set_windows(ped[:, 3][None, :], np.array([dp0]))
         plan.run()
