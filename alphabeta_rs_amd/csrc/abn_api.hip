@@ -219,7 +219,8 @@ constexpr size_t kLdsResidentMax = 40 * 1024;
 constexpr long long kPersistWaves = ABN_PERSIST_WAVES;  // wavefronts of a persistent launch: 3 per SIMD x 4 SIMDs x 256 CUs
 // A launch that would just about fill the resident wavefronts (2048 < wavefronts <= 3072: C3's 10 000 bootstraps are 2500)
 // runs persistent on 2048 of them instead: the last fifth of the chains waits in the queue, finished groups refill and
-// time slicing evens out the tail (C3 phase B 2.61 -> 2.53 ms; 1792 / 2304 wavefronts: 2.71 / 2.82 ms; round 3)
+// time slicing evens out the tail (C3 phase B 2.58 -> 2.44 ms; same box: 2.61 -> 2.53 ms, 1792 / 2304 wavefronts 2.71 /
+// 2.82 ms; profiles/r03_persist_waves_sweep.txt)
 #ifndef ABN_PERSIST_WAVES_SMALL
 #define ABN_PERSIST_WAVES_SMALL 2048
 #endif
@@ -1745,9 +1746,14 @@ static int pairwise_on_device(abn_ctx* c, const uint8_t* dcodes, int n, long lon
   DevBuf<unsigned long long> partial;
   DevBuf<uint32_t> tab;
   const size_t cols = (size_t)2 * pp.a.npairs;
-  HIPCHK(c, partial.alloc((size_t)pp.rows * cols));
+  // LDS sums: a packed row per workgroup and flush (one flush unless a workgroup sees more than 2^30 sites: then the
+  // rows some workgroups do not reach must read as zero); global atomics: one unpacked row
+  const long long wg_sites = ((pp.a.ntiles + pp.grid - 1) / pp.grid) * 32ll * pp.a.WT;
+  const int flushes = pp.a.red_in_lds ? (int)(wg_sites >> 30) + 1 : 1;
+  const size_t nrows = pp.a.red_in_lds ? (size_t)pp.rows * (size_t)flushes : 1;
+  HIPCHK(c, partial.alloc(pp.a.red_in_lds ? nrows * (size_t)pp.a.npairs : cols));
   HIPCHK(c, tab.alloc(pp.item_tab.size()));
-  if (!pp.a.red_in_lds) HIPCHK(c, hipMemsetAsync(partial.p, 0, partial.bytes(), c->stream));  // else every row is written
+  if (!pp.a.red_in_lds || flushes > 1) HIPCHK(c, hipMemsetAsync(partial.p, 0, partial.bytes(), c->stream));
   HIPCHK(c, hipMemcpyAsync(tab.p, pp.item_tab.data(), tab.bytes(), hipMemcpyHostToDevice, c->stream));
   pp.a.partial = partial.p;
   pp.a.item_tab = tab.p;
@@ -1772,9 +1778,13 @@ static int pairwise_on_device(abn_ctx* c, const uint8_t* dcodes, int n, long lon
     HIPCHK(c, hipGetLastError());
   }
   // (no sites: zero rows are summed and every pair is 0 / 0)
-  hipLaunchKernelGGL(abn_pairwise_reduce_kernel, dim3((unsigned)((cols + kPairReduceCols - 1) / kPairReduceCols)),
-                     dim3(kPairReduceCols * kPairReduceGroups), 0, c->stream, partial.p, L > 0 ? pp.rows : 0, (int)cols,
-                     ddiff, dboth, ddval);
+  const dim3 rgrid((unsigned)((cols + kPairReduceCols - 1) / kPairReduceCols)), rblock(kPairReduceCols * kPairReduceGroups);
+  if (pp.a.red_in_lds)
+    hipLaunchKernelGGL(abn_pairwise_reduce_kernel<true>, rgrid, rblock, 0, c->stream, partial.p, L > 0 ? (int)nrows : 0,
+                       pp.a.npairs, ddiff, dboth, ddval);
+  else
+    hipLaunchKernelGGL(abn_pairwise_reduce_kernel<false>, rgrid, rblock, 0, c->stream, partial.p, L > 0 ? 1 : 0,
+                       pp.a.npairs, ddiff, dboth, ddval);
   HIPCHK(c, hipGetLastError());
   if (kernel_ms) {
     HIPCHK(c, hipEventRecord(e1, c->stream));

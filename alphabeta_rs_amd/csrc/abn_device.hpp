@@ -2362,7 +2362,8 @@ struct PairArgs {
   int npairs;
   int red_in_lds;        // per-workgroup sums in LDS (else global atomics on `partial` row 0)
   const uint32_t* item_tab;     // [items] first samples of the two blocks: i0 | j0 << 16
-  unsigned long long* partial;  // [gridDim.x][2 * npairs] (diff, both) — or [1][2 * npairs] with atomics
+  unsigned long long* partial;  // red_in_lds: [flushes x gridDim.x][npairs] packed both << 32 | diff (a workgroup's sums
+                                // of at most 2^30 sites: both halves fit); else [1][2 * npairs] (diff, both) with atomics
   int dbg;                      // measurement aid: 1 = skip the pair phase, 2 = skip the staging
 };
 
@@ -2464,18 +2465,16 @@ __global__ __launch_bounds__(kPairThreads, BS == 2 ? 4 : 3) void abn_pairwise_bi
   if (a.red_in_lds)
     for (int k = tid; k < a.npairs; k += kPairThreads) red[k] = 0ull;
 
-  bool row_written = false;
-  auto flush_red = [&]() {  // LDS sums -> this workgroup's row (nobody else writes it; the first flush initialises it)
-    __syncthreads();
+  int flush_no = 0;
+  auto flush_red = [&]() {  // LDS sums -> a row of this workgroup's own (one per flush), still packed both << 32 | diff:
+    __syncthreads();        // half the bytes of two 64-bit sums, here and in the reduce kernel
     if (a.red_in_lds) {
-      unsigned long long* row = a.partial + (size_t)blockIdx.x * (size_t)(2 * a.npairs);
+      unsigned long long* row = a.partial + ((size_t)flush_no * gridDim.x + blockIdx.x) * (size_t)a.npairs;
       for (int k = tid; k < a.npairs; k += kPairThreads) {
-        const unsigned long long v = red[k];
-        row[2 * k] = (row_written ? row[2 * k] : 0ull) + (v & 0xffffffffull);
-        row[2 * k + 1] = (row_written ? row[2 * k + 1] : 0ull) + (v >> 32);
+        row[k] = red[k];
         red[k] = 0ull;
       }
-      row_written = true;
+      ++flush_no;
     }
     __syncthreads();
   };
@@ -2568,22 +2567,32 @@ __global__ __launch_bounds__(kPairThreads, BS == 2 ? 4 : 3) void abn_pairwise_bi
   flush_red();
 }
 
-// partial[rows][cols = 2 * npairs] -> diff[p], both[p], dvalue[p] = diff / (2 both) in f64 (:257; 0/0 = NaN like the
-// reference); any of the three may be null.  A workgroup owns 16 columns (8 pairs): 64 row groups of 16 threads sum
-// their rows (128-byte coalesced reads, eight in flight per thread), LDS combines the groups.  No atomics.  (Narrow
-// column blocks on purpose: 1225 pairs are 154 workgroups; with 64 columns each the 39 workgroups of that shape left
-// most of the chip idle, 8.1 us for 15 MB.)
+// partial rows -> diff[p], both[p], dvalue[p] = diff / (2 both) in f64 (:257; 0/0 = NaN like the reference); any of
+// the three may be null.  A workgroup owns 16 columns (8 pairs): 64 row groups of 16 threads sum their rows (eight
+// loads in flight per thread), LDS combines the groups.  No atomics.  (Narrow column blocks on purpose: 1225 pairs are
+// 154 workgroups; with 64 columns each the 39 workgroups of that shape left most of the chip idle.)
+// PACKED (per-workgroup rows from LDS sums): partial[rows][npairs], one word both << 32 | diff per pair — a workgroup owns
+// 8 pairs, thread (pair, half) sums one 32-bit half of its column into 64 bits.  Else (global atomics, one row):
+// partial[rows][2 * npairs] (diff, both).  Same thread layout: 16 "columns" x 64 row groups.
 constexpr int kPairReduceCols = 16, kPairReduceGroups = 64;
+template <bool PACKED>
 __global__ __launch_bounds__(kPairReduceCols * kPairReduceGroups) void abn_pairwise_reduce_kernel(
-    const unsigned long long* partial, int rows, int cols, unsigned long long* diff, unsigned long long* both,
+    const unsigned long long* partial, int rows, int npairs, unsigned long long* diff, unsigned long long* both,
     double* dvalue) {
   __shared__ unsigned long long part[kPairReduceGroups][kPairReduceCols];
   const int cx = threadIdx.x & (kPairReduceCols - 1), g = threadIdx.x / kPairReduceCols;
-  const int c = blockIdx.x * kPairReduceCols + cx;
+  const int c = blockIdx.x * kPairReduceCols + cx;   // column 2 p (diff) / 2 p + 1 (both) of pair p
+  const int cols = 2 * npairs;
   unsigned long long acc = 0;
   if (c < cols) {
+    if constexpr (PACKED) {
+      const int sh = (cx & 1) ? 32 : 0;
 #pragma unroll 8
-    for (int r = g; r < rows; r += kPairReduceGroups) acc += partial[(size_t)r * (size_t)cols + c];
+      for (int r = g; r < rows; r += kPairReduceGroups) acc += (partial[(size_t)r * (size_t)npairs + (c >> 1)] >> sh) & 0xffffffffull;
+    } else {
+#pragma unroll 8
+      for (int r = g; r < rows; r += kPairReduceGroups) acc += partial[(size_t)r * (size_t)cols + c];
+    }
   }
   part[g][cx] = acc;
   __syncthreads();
