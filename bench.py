@@ -249,11 +249,12 @@ def quick_workload(A, ctx, name, seed, steps=3, **options):
     return r
 
 
-def pairwise_bench(A, ctx, shapes=((15, 4_000_000), (50, 2_000_000)), reps=5):
+def pairwise_bench(A, ctx, shapes=((15, 4_000_000), (15, 32_000_000), (50, 32_000_000), (50, 2_000_000)), reps=5):
     """SURVEY §8(f).1, `DMatrix::from` (src/pedigree.rs:210-261): pairwise divergence of n samples over L aligned
     sites, codes RESIDENT in HBM (one byte per sample and site).  One pass over the codes is the algorithmic traffic:
     n*L bytes / kernel time against the HBM peak; the pair arithmetic (n(n-1)/2 pairs x L sites) is reported as
-    site-pairs/s next to it."""
+    site-pairs/s next to it.  Shapes: the two of round 2 (the last one, 50 x 2 M, is the `pw` line's value) and the same
+    sample counts at genome scale (32 M sites), where a workgroup sees ~40 tiles instead of 2.5."""
     import torch
 
     out = []
