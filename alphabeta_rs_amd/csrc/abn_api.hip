@@ -412,7 +412,7 @@ static bool spec_applicable(const FitArgs& a) {
   const int rmax = pick_rmax(a.N, kWave);
   if (rmax == 0 || rmax > 8) return false;  // 16 rows per lane: the plain resident kernel
   if (!tree_on_wave_ok(a.N, a.chain_stride, a.tree)) return false;
-  const int np = (a.N + 1) & ~1;
+  const int np = ((a.N + 1) & ~1) * (a.strict ? 2 : 1);   // observations (+ strict order: the rows' terms)
   return (3 * (size_t)(a.chain_stride + np) + kSpecCommDoubles) * sizeof(double) <= kLdsResidentMax;
 }
 
@@ -420,15 +420,24 @@ static int launch_fit_spec(abn_ctx* c, FitArgs a, hipStream_t st) {
   const long long chains = (long long)a.W * a.C;
   if (chains <= 0) return ABN_OK;
   const int rmax = pick_rmax(a.N, kWave);
-  a.chain_stride += (a.N + 1) & ~1;
+  a.chain_stride += ((a.N + 1) & ~1) * (a.strict ? 2 : 1);
   const size_t lds = (3 * (size_t)a.chain_stride + kSpecCommDoubles) * sizeof(double);
   dim3 grid((unsigned)chains), block(4 * kWave);
-  a.tree = kTreeCanon;  // spec_applicable admitted it
-  switch (rmax) {
-    case 1: hipLaunchKernelGGL(abn_fit_spec_kernel<1>, grid, block, lds, st, a); break;
-    case 2: hipLaunchKernelGGL(abn_fit_spec_kernel<2>, grid, block, lds, st, a); break;
-    case 4: hipLaunchKernelGGL(abn_fit_spec_kernel<4>, grid, block, lds, st, a); break;
-    default: hipLaunchKernelGGL(abn_fit_spec_kernel<8>, grid, block, lds, st, a); break;
+  a.tree = a.strict ? 1 : kTreeCanon;  // spec_applicable admitted it
+  if (a.strict) {
+    switch (rmax) {
+      case 1: hipLaunchKernelGGL((abn_fit_spec_kernel<1, true>), grid, block, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((abn_fit_spec_kernel<2, true>), grid, block, lds, st, a); break;
+      case 4: hipLaunchKernelGGL((abn_fit_spec_kernel<4, true>), grid, block, lds, st, a); break;
+      default: hipLaunchKernelGGL((abn_fit_spec_kernel<8, true>), grid, block, lds, st, a); break;
+    }
+  } else {
+    switch (rmax) {
+      case 1: hipLaunchKernelGGL((abn_fit_spec_kernel<1, false>), grid, block, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((abn_fit_spec_kernel<2, false>), grid, block, lds, st, a); break;
+      case 4: hipLaunchKernelGGL((abn_fit_spec_kernel<4, false>), grid, block, lds, st, a); break;
+      default: hipLaunchKernelGGL((abn_fit_spec_kernel<8, false>), grid, block, lds, st, a); break;
+    }
   }
   HIPCHK(c, hipGetLastError());
   return ABN_OK;
@@ -1106,13 +1115,13 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   if (timed) HIPCHK(c, hipEventRecord(p->ev[0], st));
   // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once,
   // a fourth keeps the simplex and prepares the next candidates meanwhile (abn_fit_spec_kernel)
-  bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 && !a.strict &&
+  bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 &&
               (long long)p->W * p->S <= spec_max_chains(p->N) && spec_applicable(a);
   int lanes_a = p->lanes_a;
 #ifdef ABN_MEASUREMENT_KNOBS  // ABN_PHASE_A_KERNEL = spec | wide | packed  (scripts/phase_a_sweep.py)
   if (const char* e = getenv("ABN_PHASE_A_KERNEL")) {
     const bool can_wide = p->opt.lanes_per_chain == 0 && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree);
-    if (!strcmp(e, "spec")) spec = can_wide && !a.strict && spec_applicable(a);
+    if (!strcmp(e, "spec")) spec = can_wide && spec_applicable(a);
     if (!strcmp(e, "wide")) { spec = false; if (can_wide) lanes_a = kWave; }
     if (!strcmp(e, "packed")) { spec = false; lanes_a = p->lanes; }
   }
@@ -1222,7 +1231,7 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
     a.D = dst;
   }
   // few bootstraps: latency-bound like phase A -> the speculative kernel (four wavefronts per chain)
-  bool spec = a.dmode == 1 && p->opt.lanes_per_chain == 0 && !a.strict &&
+  bool spec = a.dmode == 1 && p->opt.lanes_per_chain == 0 &&
               (long long)p->W * p->B <= spec_max_chains(p->N) && spec_applicable(a);
   int lanes_b = p->lanes;
   // ... and up to 192 chains per packed lane (3072 for the 16-lane kernels) a wavefront per chain still beats packing
@@ -1234,7 +1243,7 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
 #ifdef ABN_MEASUREMENT_KNOBS  // ABN_PHASE_B_KERNEL = spec | wide | packed
   if (const char* e = getenv("ABN_PHASE_B_KERNEL")) {
     const bool can_wide = a.dmode == 1 && p->opt.lanes_per_chain == 0 && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree);
-    if (!strcmp(e, "spec")) spec = can_wide && !a.strict && spec_applicable(a);
+    if (!strcmp(e, "spec")) spec = can_wide && spec_applicable(a);
     if (!strcmp(e, "wide")) { spec = false; if (can_wide) lanes_b = kWave; }
     if (!strcmp(e, "packed")) spec = false;
   }

@@ -1602,7 +1602,9 @@ constexpr int kSpecPreDoubles = kSpecOutcomes * 3 * 12;             // [outcome]
 constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16 + 2 * kSpecPreDoubles + 16;  // cost exchange, two candidate
                                                  // tables, shrink points, two tables of prepared inputs, two control blocks
 
-template <int RMAX>
+// STRICT (abn_options.strict_order): the evaluation wavefronts sum the residuals serially in row order (terms to LDS, N
+// more doubles per wavefront, then serial_sum_lds) — the reference's order, the oracle's lanes = 1.
+template <int RMAX, bool STRICT = false>
 __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_kernel(const FitArgs a) {
   constexpr int G = kWave;
   extern __shared__ __align__(16) double lds[];
@@ -1727,14 +1729,26 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
       dv[q] = in ? dobs[gl + G * q] : 0.0;
       tv[q] = in ? dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu] : 0.0;
     }
+    if constexpr (STRICT) {   // `square_sum += ...` in row order, src/structs.rs:206-213
+      double* term = dobs + ((N + 1) & ~1);
 #pragma unroll
-    for (int q = 0; q < RMAX; ++q) {
-      if ((gl + G * q) < N) {
-        const double r = dv[q] - ic - tv[q];
-        acc = acc + (r * r + pen);
+      for (int q = 0; q < RMAX; ++q) {
+        if ((gl + G * q) < N) {
+          const double r = dv[q] - ic - tv[q];
+          term[gl + G * q] = r * r + pen;
+        }
       }
-    }
-    {  // P5: the canonical tree (this kernel runs under auto options only: FitArgs::tree == kTreeCanon)
+      wave_lds_fence();
+      acc = serial_sum_lds(term, N, 0.0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < RMAX; ++q) {
+        if ((gl + G * q) < N) {
+          const double r = dv[q] - ic - tv[q];
+          acc = acc + (r * r + pen);
+        }
+      }
+      // P5: the canonical tree (without strict order this kernel runs under auto options only: FitArgs::tree == kTreeCanon)
       const double one[1] = {acc};
       acc = tree64_finish<G>(one);
     }

@@ -26,7 +26,7 @@ static void usage() {
       "      --devices <A,B,..>         several HIP devices: the bootstraps are sharded over them, tables gathered with RCCL\n"
       "      --lanes <G>                lanes of a wavefront per Nelder-Mead chain: 0 (auto), 8, 16, 32, 64\n"
       "      --strict-order             sum every cost's residuals serially in row order, exactly as the reference does\n"
-      "                                 (src/structs.rs:206-213): bit-equal to a reference-order CPU run, ~1.7x the time\n"
+      "                                 (src/structs.rs:206-213): bit-equal to a reference-order CPU run, ~1.5x the time\n"
       "      --pedigree <FILE>          use this pedigree file (src/pedigree.rs:62-79 format) instead of building one\n"
       "      --p0uu <X>                 proportion of unmethylated sites at G0 (required with --pedigree)\n"
       "  -h, --help                     Print help\n"
