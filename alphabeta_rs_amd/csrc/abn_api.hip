@@ -360,6 +360,17 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, int* kin
                       blocks > kPersistWavesSmall;
   if (refill) blocks = persist_waves_for(blocks);
   if (!refill) a.quantum = 0;
+#ifdef ABN_MEASUREMENT_KNOBS  // scripts/prio_sweep.sh: wave priority by chain age, wavefronts and quantum of the persistent launch
+  if (refill) {
+    if (const char* e = getenv("ABN_PRIO")) sscanf(e, "%d,%d,%d,%d", &a.prio_mode, &a.prio_t[0], &a.prio_t[1], &a.prio_t[2]);
+    if (const char* e = getenv("ABN_PERSIST_WAVES_SMALL_ENV")) {
+      if (blocks == kPersistWavesSmall) blocks = std::max(64, atoi(e));
+    }
+    if (const char* e = getenv("ABN_QUANTUM_ENV")) {
+      if (a.quantum > 0) a.quantum = std::max(16, atoi(e));
+    }
+  }
+#endif
   if (refill && a.slice_status) HIPCHK(c, hipMemsetAsync(a.slice_status, 0, 2 * sizeof(unsigned), st));
   if (kind)
     *kind = refill ? ABN_KERNEL_PERSISTENT

@@ -139,6 +139,10 @@ struct FitArgs {
   // idle, the chain's outputs stay unwritten), slice_status[1] += chains finished (results written).  The host compares
   // the count with W x C after a time-sliced launch: a lost or never-resumed chain is an error, not stale output.
   unsigned* slice_status;
+  // Wave priority by chain age in the persistent kernel (prio_mode != 0): the wavefront's s_setprio level is the number of
+  // thresholds prio_t[] that the evaluations of its OLDEST running chain have passed (mode 1), or 3 minus that (mode 2).
+  int prio_mode;
+  int prio_t[3];
   double sd_tol;
   double gap_tol;        // 64 * sd_tol, precomputed on the host so that it stays a scalar (kernarg) operand
   // outputs (fit order)
@@ -1387,7 +1391,26 @@ __global__ __launch_bounds__(kWave, ABN_REFILL_MIN_WAVES) void abn_fit_refill_ke
     st = done ? ST_DONE : ST_REFLECT;
   };
 
+  int prio_cur = 0;
   while (__ballot(st != ST_IDLE) != 0ull) {
+    if (a.prio_mode != 0) {  // wave priority by the age of the wavefront's oldest running chain (scalar code)
+      const int e = st != ST_IDLE ? evals : 0;
+      int m = 0;
+#pragma unroll
+      for (int j = 0; j < NG; ++j) {
+        const int ej = __builtin_amdgcn_readlane(e, j * G);
+        m = ej > m ? ej : m;
+      }
+      int lvl = (m >= a.prio_t[0] ? 1 : 0) + (m >= a.prio_t[1] ? 1 : 0) + (m >= a.prio_t[2] ? 1 : 0);
+      if (a.prio_mode == 2) lvl = 3 - lvl;
+      if (lvl != prio_cur) {
+        prio_cur = lvl;
+        if (lvl == 0) __builtin_amdgcn_s_setprio(0);
+        else if (lvl == 1) __builtin_amdgcn_s_setprio(1);
+        else if (lvl == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+      }
+    }
     const bool in_init = st < ST_REFLECT;                         // Solver::init: start vertex st - ST_INIT0
     const double f = eval(in_init ? vx[0] : xc);
     // ---- decisions of NelderMead::next_iter as predicates (inert for groups in init or idle)
