@@ -16,6 +16,7 @@
 
 #include "../../include/abneutral.h"
 #include "abn_device.hpp"
+#include "abn_pairwise_mx.hpp"
 
 using namespace abn;
 
@@ -1681,131 +1682,85 @@ extern "C" int abn_bootstrap_rows(abn_ctx* c, const double* best, int64_t n_boot
 // ------------------------------------------------------------------------------------------------
 // pedigree construction: pairwise divergence (src/pedigree.rs:210-261)
 // ------------------------------------------------------------------------------------------------
-// launch configuration of abn_pairwise_bits_kernel for n samples
-struct PairPlan {
-  PairArgs a{};
-  size_t lds = 0;
-  unsigned grid = 0;
-  int rows = 0;  // rows of `partial`
-  int bs = 2;    // samples per block
-  std::vector<uint32_t> item_tab;
-};
+// Exact integer Gram products on the matrix pipe (abn_pairwise_mx.hpp): any number of samples, the sample axis tiled in
+// groups of 64; codes already on the device, outputs on the device (any may be null).
+constexpr long long kPmxMaxJobs = 8192;  // jobs per launch: 32 KiB of packed sums each (256 MiB of `partial`)
 
-static int plan_pairwise(abn_ctx* c, int n, long long L, PairPlan& pp) {
-  PairArgs& a = pp.a;
-  if (n > 65535) return set_err(c, ABN_ERR_INVALID_ARG, "too many samples");
-  a.n = n;
-  a.L = L;
-  a.npairs = n * (n - 1) / 2;
-  // samples per block: 4 x 4 pairs per unit halve the LDS traffic per instruction but need enough samples to keep 256
-  // threads busy (n = 15: ten 4 x 4 blocks against thirty-six 2 x 2 blocks)
-  int bs = n >= 32 ? 4 : 2;
-#ifdef ABN_MEASUREMENT_KNOBS  // scripts/pw_sweep.sh builds with this: block size, slices, grid and phase switches from the environment
-  if (const char* e = getenv("ABN_PAIR_BLOCK")) bs = atoi(e) == 4 ? 4 : 2;
-#endif
-  pp.bs = bs;
-  a.nb = (n + bs - 1) / bs;
-  a.items = a.nb * (a.nb + 1) / 2;
-  a.red_in_lds = a.npairs <= kPairLdsRedMax ? 1 : 0;
-  const size_t red_bytes = a.red_in_lds ? (size_t)a.npairs * sizeof(unsigned long long) + 8 : 0;
-  // tile: the largest power-of-two number of 32-site words per sample (<= 256) whose three planes fit ~40 KiB of LDS
-  // next to the per-pair sums, so that four workgroups share a CU's 160 KiB ...
-  int wt = 256;
-  auto bytes = [&](int w) { return (size_t)3 * a.nb * (bs * w + 4) * sizeof(uint32_t) + red_bytes; };
-  while (wt > 4 && bytes(wt) > 40 * 1024) wt >>= 1;
-  // ... up to the CU's whole LDS for very many samples (the launch opts in with hipFuncAttributeMaxDynamicSharedMemorySize):
-  // one tile of four words per sample holds ~2700 samples (the reference's DMatrix::from has no limit; beyond that the
-  // planes of one tile no longer fit a workgroup)
-  if (bytes(wt) > kMaxDynLds) return set_err(c, ABN_ERR_INVALID_ARG, "too many samples for one LDS tile (> ~2700)");
-  // ... and small enough that every workgroup sees a few tiles
-  while (wt > 32 && (L + 32ll * wt - 1) / (32ll * wt) < 256LL * 4) wt >>= 1;
-  a.WT = wt;
-  pp.lds = bytes(wt);
-  // work units = pair blocks x slices of a tile's words (slices are multiples of four words): enough units that the
-  // round-robin over 256 threads wastes little (>= 90 % of the thread-passes busy), as few slices as that takes
-  const int smax = wt / 4;
-  int S = 1;
-  for (int s = 1; s <= smax; s *= 2) {
-    const long long units = (long long)a.items * s;
-    const long long passes = (units + kPairThreads - 1) / kPairThreads;
-    S = s;
-    // every unit ends with one LDS atomic per pair: stop at the first slicing that keeps 70 % of the thread-passes busy
-    if ((double)units / (double)(passes * kPairThreads) >= 0.7) break;
+template <bool AL4>
+static hipError_t launch_pairwise_mx(int nb, bool diag, unsigned grid, hipStream_t s, const PairMxArgs& a) {
+  if (!diag) {
+    hipLaunchKernelGGL((abn_pairwise_mx_kernel<4, false, AL4>), dim3(grid), dim3(kPmxThreads), 0, s, a);
+  } else {
+    switch (nb) {
+      case 1: hipLaunchKernelGGL((abn_pairwise_mx_kernel<1, true, AL4>), dim3(grid), dim3(kPmxThreads), 0, s, a); break;
+      case 2: hipLaunchKernelGGL((abn_pairwise_mx_kernel<2, true, AL4>), dim3(grid), dim3(kPmxThreads), 0, s, a); break;
+      case 3: hipLaunchKernelGGL((abn_pairwise_mx_kernel<3, true, AL4>), dim3(grid), dim3(kPmxThreads), 0, s, a); break;
+      default: hipLaunchKernelGGL((abn_pairwise_mx_kernel<4, true, AL4>), dim3(grid), dim3(kPmxThreads), 0, s, a); break;
+    }
   }
-#ifdef ABN_MEASUREMENT_KNOBS
-  if (const char* e = getenv("ABN_PAIR_SLICES")) {
-    const int sl = atoi(e);
-    if (sl >= 1 && sl <= smax && (wt / 4) % sl == 0) S = sl;
+  return hipGetLastError();
+}
+
+// One family of super-pairs (the ngroups diagonal ones, or the pairs R < C), in slabs of at most kPmxMaxJobs jobs: each
+// slab is a scan launch and a reduce launch that writes its pairs of the result.
+static int pairwise_mx_family(abn_ctx* c, PairMxArgs a, bool diag, long long nsp, int nb, bool al4, long long cu_jobs,
+                              DevBuf<unsigned long long>& partial, unsigned long long* ddiff, unsigned long long* dboth,
+                              double* ddval) {
+  if (nsp <= 0) return ABN_OK;
+  (void)nb;
+  // chunks per super-pair: enough jobs to fill the GPU (cu_jobs workgroups per CU), every wavefront at least a few K
+  // steps of 64 sites, and no chunk beyond 2^30 sites (the packed 32-bit halves of a job's sums)
+  const long long nk = (a.L + 63) / 64;
+  long long nchunks = std::max<long long>(1, (256 * cu_jobs + nsp - 1) / nsp);
+  nchunks = std::min<long long>(nchunks, std::max<long long>(1, nk / (4 * kPmxWaves)));
+  nchunks = std::max<long long>(nchunks, (a.L >> 30) + 1);
+  if (a.L == 0) nchunks = 1;
+  a.nchunks = (int)nchunks;
+  const long long slab = std::max<long long>(1, kPmxMaxJobs / nchunks);
+  HIPCHK(c, partial.alloc((size_t)std::min(slab, nsp) * (size_t)nchunks * kPmxJobElems));
+  a.partial = partial.p;
+  for (long long s0 = 0; s0 < nsp; s0 += slab) {
+    const long long ns = std::min(slab, nsp - s0);
+    a.first = s0;
+    if (a.L > 0)
+      HIPCHK(c, al4 ? launch_pairwise_mx<true>(nb, diag, (unsigned)(ns * nchunks), c->stream, a)
+                    : launch_pairwise_mx<false>(nb, diag, (unsigned)(ns * nchunks), c->stream, a));
+    // (no sites: zero rows are summed and every pair is 0 / 0)
+    hipLaunchKernelGGL(abn_pairwise_reduce_tiles_kernel, dim3((unsigned)(ns * 256)), dim3(16 * kPmxReduceGroups), 0,
+                       c->stream, partial.p, a.L > 0 ? (int)nchunks : 0, a.n, a.ngroups, diag ? 1 : 0, s0, ddiff, dboth,
+                       ddval);
+    HIPCHK(c, hipGetLastError());
   }
-  if (const char* e = getenv("ABN_PAIR_DEBUG")) a.dbg = atoi(e);
-#endif
-  a.S = S;
-  a.units = a.items * S;
-  a.ntiles = (L + 32ll * wt - 1) / (32ll * wt);
-  const long long per_cu = std::max<long long>(1, std::min<long long>((160 * 1024) / (long long)pp.lds, bs == 4 ? 3 : 4));
-  long long cu_blocks = per_cu;
-#ifdef ABN_MEASUREMENT_KNOBS
-  if (const char* e = getenv("ABN_PAIR_GRID")) cu_blocks = std::max(1, atoi(e));
-#endif
-  pp.grid = (unsigned)std::max<long long>(1, std::min<long long>(a.ntiles, 256LL * cu_blocks));  // persistent workgroups
-  pp.rows = a.red_in_lds ? (int)pp.grid : 1;
-  pp.item_tab.clear();
-  pp.item_tab.reserve((size_t)a.items);
-  for (int I = 0; I < a.nb; ++I)
-    for (int J = I; J < a.nb; ++J) pp.item_tab.push_back((uint32_t)(bs * I) | ((uint32_t)(bs * J) << 16));
   return ABN_OK;
 }
 
-// codes already on the device; outputs on the device (any may be null)
-static int pairwise_on_device(abn_ctx* c, const uint8_t* dcodes, int n, long long L, unsigned long long* ddiff,
-                              unsigned long long* dboth, double* ddval, double* kernel_ms) {
-  PairPlan pp;
-  int rc = plan_pairwise(c, n, L, pp);
-  if (rc) return rc;
-  pp.a.codes = dcodes;
-  DevBuf<unsigned long long> partial;
-  DevBuf<uint32_t> tab;
-  const size_t cols = (size_t)2 * pp.a.npairs;
-  // LDS sums: a packed row per workgroup and flush (one flush unless a workgroup sees more than 2^30 sites: then the
-  // rows some workgroups do not reach must read as zero); global atomics: one unpacked row
-  const long long wg_sites = ((pp.a.ntiles + pp.grid - 1) / pp.grid) * 32ll * pp.a.WT;
-  const int flushes = pp.a.red_in_lds ? (int)(wg_sites >> 30) + 1 : 1;
-  const size_t nrows = pp.a.red_in_lds ? (size_t)pp.rows * (size_t)flushes : 1;
-  HIPCHK(c, partial.alloc(pp.a.red_in_lds ? nrows * (size_t)pp.a.npairs : cols));
-  HIPCHK(c, tab.alloc(pp.item_tab.size()));
-  if (!pp.a.red_in_lds || flushes > 1) HIPCHK(c, hipMemsetAsync(partial.p, 0, partial.bytes(), c->stream));
-  HIPCHK(c, hipMemcpyAsync(tab.p, pp.item_tab.data(), tab.bytes(), hipMemcpyHostToDevice, c->stream));
-  pp.a.partial = partial.p;
-  pp.a.item_tab = tab.p;
+static int pairwise_mx_on_device(abn_ctx* c, const uint8_t* dcodes, int n, long long L, unsigned long long* ddiff,
+                                 unsigned long long* dboth, double* ddval, double* kernel_ms) {
+  if (n > 65535) return set_err(c, ABN_ERR_INVALID_ARG, "too many samples");
+  PairMxArgs a{};
+  a.codes = dcodes;
+  a.n = n;
+  a.L = L;
+  a.ngroups = (n + 63) / 64;
+  const bool al4 = (L % 4 == 0) && ((uintptr_t)dcodes % 4 == 0);
+  const int nb = a.ngroups == 1 ? (n + 15) / 16 : 4;
+  DevBuf<unsigned long long> pdiag, poff;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (kernel_ms) {
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
-  if (L > 0) {
-    if (pp.bs == 4) {
-      if (pp.lds > 48 * 1024)
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(abn_pairwise_bits_kernel<4>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.lds));
-      hipLaunchKernelGGL(abn_pairwise_bits_kernel<4>, dim3(pp.grid), dim3(kPairThreads), pp.lds, c->stream, pp.a);
-    } else {
-      if (pp.lds > 48 * 1024)
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(abn_pairwise_bits_kernel<2>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp.lds));
-      hipLaunchKernelGGL(abn_pairwise_bits_kernel<2>, dim3(pp.grid), dim3(kPairThreads), pp.lds, c->stream, pp.a);
-    }
-    HIPCHK(c, hipGetLastError());
-  }
-  // (no sites: zero rows are summed and every pair is 0 / 0)
-  const dim3 rgrid((unsigned)((cols + kPairReduceCols - 1) / kPairReduceCols)), rblock(kPairReduceCols * kPairReduceGroups);
-  if (pp.a.red_in_lds)
-    hipLaunchKernelGGL(abn_pairwise_reduce_kernel<true>, rgrid, rblock, 0, c->stream, partial.p, L > 0 ? (int)nrows : 0,
-                       pp.a.npairs, ddiff, dboth, ddval);
-  else
-    hipLaunchKernelGGL(abn_pairwise_reduce_kernel<false>, rgrid, rblock, 0, c->stream, partial.p, L > 0 ? 1 : 0,
-                       pp.a.npairs, ddiff, dboth, ddval);
-  HIPCHK(c, hipGetLastError());
+  // workgroups per CU: two (eight wavefronts streaming per CU) once the scan is long enough to pay for twice the partial
+  // rows; one below (50 x 2 M sites: 28.6 against 30.5 us; 50 x 32 M: 304 against 282 us)
+  long long cu_diag = (long long)n * L >= (256ll << 20) ? 2 : 1, cu_off = 1;
+#ifdef ABN_MEASUREMENT_KNOBS
+  if (const char* e = getenv("ABN_PMX_CU_JOBS")) cu_diag = cu_off = std::max(1, atoi(e));
+#endif
+  const long long g = a.ngroups;
+  int rc = pairwise_mx_family(c, a, true, g, nb, al4, cu_diag, pdiag, ddiff, dboth, ddval);
+  if (!rc) rc = pairwise_mx_family(c, a, false, g * (g - 1) / 2, 4, al4, cu_off, poff, ddiff, dboth, ddval);
+  if (rc) return rc;
   if (kernel_ms) {
     HIPCHK(c, hipEventRecord(e1, c->stream));
     HIPCHK(c, hipEventSynchronize(e1));
@@ -1815,7 +1770,7 @@ static int pairwise_on_device(abn_ctx* c, const uint8_t* dcodes, int n, long lon
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // partial / tab (and the host table) are freed on return
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the partial rows are freed on return
   return ABN_OK;
 }
 
@@ -1826,7 +1781,7 @@ extern "C" int abn_pairwise_divergence_dev(abn_ctx* c, const void* dev_codes, in
   if (n_samples < 2) return ABN_OK;
   HIPCHK(c, hipSetDevice(c->device));
   PoolScope pool_scope(c);
-  return pairwise_on_device(c, (const uint8_t*)dev_codes, n_samples, n_sites, (unsigned long long*)dev_diff,
+  return pairwise_mx_on_device(c, (const uint8_t*)dev_codes, n_samples, n_sites, (unsigned long long*)dev_diff,
                             (unsigned long long*)dev_both, (double*)dev_dvalue, kernel_ms);
 }
 
@@ -1847,7 +1802,7 @@ extern "C" int abn_pairwise_divergence(abn_ctx* c, const uint8_t* codes, int32_t
   HIPCHK(c, ddv.alloc(npairs));
   if (n_sites > 0)
     HIPCHK(c, hipMemcpyAsync(dcodes.p, codes, n * (size_t)n_sites, hipMemcpyHostToDevice, c->stream));
-  int rc = pairwise_on_device(c, dcodes.p, n_samples, n_sites, ddiff.p, dboth.p, ddv.p, nullptr);
+  int rc = pairwise_mx_on_device(c, dcodes.p, n_samples, n_sites, ddiff.p, dboth.p, ddv.p, nullptr);
   if (rc) return rc;
   if (diff) HIPCHK(c, hipMemcpyAsync(diff, ddiff.p, ddiff.bytes(), hipMemcpyDeviceToHost, c->stream));
   if (both) HIPCHK(c, hipMemcpyAsync(both, dboth.p, dboth.bytes(), hipMemcpyDeviceToHost, c->stream));

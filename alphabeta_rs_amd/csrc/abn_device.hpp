@@ -2358,300 +2358,6 @@ __global__ __launch_bounds__(kWave) void abn_cost_kernel(const CostArgs a) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// Pairwise divergence, DMatrix::from (src/pedigree.rs:210-261): byte/integer work, ONE pass over the codes (n x L
-// bytes; status_numeric 0 = U, 1 = I, 2 = M, | 0x80 when the site's posteriormax is below the filter).
-//
-// |status_i - status_j| over {0, 1, 2} is the Hamming distance of the thermometer codes (s >= 1, s >= 2), so with
-// three BIT PLANES per sample — t1 = (s >= 1), t2 = (s == 2), v = valid — a pair needs per 32 sites
-//     b = v_i & v_j;   diff += popc((t1_i ^ t1_j) & b) + popc((t2_i ^ t2_j) & b);   both += popc(b)       (:249-254)
-// eight vector instructions instead of eight per FOUR sites on the byte codes (the round-1 kernel: 1 % of the HBM rate).
-// A persistent workgroup of 256 threads loops over tiles of 32 WT sites:
-//   stage   every thread turns 32 consecutive bytes of one sample (two 16-byte loads, coalesced across the workgroup;
-//           byte-misaligned rows are funnel-shifted with v_alignbyte) into one 32-bit word of each plane — three masked
-//           copies per dword and one v_dot4_u32_u8 each, whose byte weights put four sites into a nibble — and stores
-//           them to LDS.  Measured alone this streams the codes at 4.5 TB/s.
-//   pairs   a work unit = a 2 x 2 block of samples (four pairs) x a slice of the tile's words; a thread reads the
-//           twelve plane rows it needs with ds_read_b128 (four words at a time), counts in registers and adds the
-//           eight counters to the tile-independent per-pair sums in LDS (ds_add_u32).  Units are dealt round-robin, so
-//           few samples still give every thread work (the words of a tile are split over threads).
-//   LDS     planes [sample block][2 rows][WT words] with a block pitch of 2 WT + 4 words: the threads of a wavefront
-//           work on consecutive sample blocks, whose 16-byte reads then start 4 banks apart and cover all 64 banks
-//           (the round-1 tile had a row pitch of 512 words, a multiple of the 64 banks).  This phase is bound by LDS
-//           bandwidth (1.5 bytes per vector instruction), not by the ALU.
-// At the end (and before a 32-bit counter could overflow) the per-pair sums are written to the workgroup's own row of
-// `partial` — plain stores, no global atomics; abn_pairwise_reduce_kernel sums the rows.  Integer sums: exact and
-// independent of the order.
-// ------------------------------------------------------------------------------------------------
-constexpr int kPairThreads = 256;
-constexpr int kPairLdsRedMax = 4096;     // pairs whose per-workgroup sums fit LDS (2 x u32 each)
-
-struct PairArgs {
-  const uint8_t* codes;
-  int n;                 // samples
-  long long L;           // sites per sample
-  int WT;                // words (of 32 sites) per tile and sample (a power of two)
-  int nb;                // sample blocks (of BS samples)
-  int items;             // block pairs I <= J
-  int S;                 // slices of a tile's words per item
-  int units;             // items * S
-  long long ntiles;
-  int npairs;
-  int red_in_lds;        // per-workgroup sums in LDS (else global atomics on `partial` row 0)
-  const uint32_t* item_tab;     // [items] first samples of the two blocks: i0 | j0 << 16
-  unsigned long long* partial;  // red_in_lds: [flushes x gridDim.x][npairs] packed both << 32 | diff (a workgroup's sums
-                                // of at most 2^30 sites: both halves fit); else [1][2 * npairs] (diff, both) with atomics
-  int dbg;                      // measurement aid: 1 = skip the pair phase, 2 = skip the staging
-};
-
-// 32 bytes of one sample -> one word of each plane, in two steps so that a thread can have the loads of several
-// chunks in flight before it converts the first (the kernel is bound by bytes in flight, not by arithmetic).
-// `valid` < 32: the chunk runs past the end of the row (those sites are invalid).  The bit order inside a word is
-// the same for every plane and sample, which is all that matters.
-struct PairRaw {
-  u32x4 lo, hi;
-  uint32_t ex;
-  int mode;  // 0: nothing to read (all invalid), 1: dword loads (+ funnel shift by `sh` bytes), 2: byte by byte
-  unsigned sh;
-};
-__device__ __forceinline__ PairRaw pair_load(const uint8_t* codes, size_t total, size_t off, int valid) {
-  PairRaw r;
-  r.lo = r.hi = u32x4{0u, 0u, 0u, 0u};
-  r.ex = 0u;
-  r.sh = (unsigned)(off & 3);
-  if (valid <= 0) {
-    r.mode = 0;
-  } else if (valid >= 32 && off + 36 <= total) {
-    const size_t base = off & ~(size_t)3;
-    r.mode = 1;
-    r.lo = *reinterpret_cast<const u32x4*>(codes + base);
-    r.hi = *reinterpret_cast<const u32x4*>(codes + base + 16);
-    if (r.sh) r.ex = *reinterpret_cast<const uint32_t*>(codes + base + 32);
-  } else {
-    r.mode = 2;
-  }
-  return r;
-}
-__device__ __forceinline__ void pair_convert(const PairRaw& r, const uint8_t* codes, size_t off, int valid, uint32_t& t1,
-                                             uint32_t& t2, uint32_t& vv) {
-  t1 = t2 = vv = 0u;
-  if (r.mode == 0) return;
-  uint32_t x[8];
-  if (r.mode == 1) {
-    const uint32_t y[9] = {r.lo[0], r.lo[1], r.lo[2], r.lo[3], r.hi[0], r.hi[1], r.hi[2], r.hi[3], r.ex};
-    if (r.sh) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) x[k] = __builtin_amdgcn_alignbyte(y[k + 1], y[k], r.sh);
-    } else {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) x[k] = y[k];
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      uint32_t w = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int i = 4 * k + e;
-        const uint32_t byte = (i < valid) ? codes[off + (size_t)i] : 0x80u;
-        w |= byte << (8 * e);
-      }
-      x[k] = w;
-    }
-  }
-  // Per dword three masked copies — valid = !flag (bytes 0x80 / 0), s == 2 = bit 1, s >= 1 = bit 1 of s + 1 (s <= 2: no
-  // carry into the flag) — and one v_dot4_u32_u8 each with the byte weights 1, 2, 4, 8 (even dwords) or 16, 32, 64, 128
-  // (odd dwords): two dwords fill one byte of the plane word, scaled by 128 (valid) or 2 (the others).
-  uint32_t sv[4] = {0u, 0u, 0u, 0u}, s2[4] = {0u, 0u, 0u, 0u}, s1[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const uint32_t w = (k & 1) ? 0x80402010u : 0x08040201u;
-    const uint32_t a = (x[k] ^ 0x80808080u) & 0x80808080u;
-    const uint32_t b = x[k] & 0x02020202u;
-    const uint32_t c = (x[k] + 0x01010101u) & 0x02020202u;
-    sv[k >> 1] = __builtin_amdgcn_udot4(a, w, sv[k >> 1], false);
-    s2[k >> 1] = __builtin_amdgcn_udot4(b, w, s2[k >> 1], false);
-    s1[k >> 1] = __builtin_amdgcn_udot4(c, w, s1[k >> 1], false);
-  }
-  vv = (sv[0] >> 7) | (sv[1] << 1) | (sv[2] << 9) | (sv[3] << 17);
-  t2 = (s2[0] >> 1) | (s2[1] << 7) | (s2[2] << 15) | (s2[3] << 23);
-  t1 = (s1[0] >> 1) | (s1[1] << 7) | (s1[2] << 15) | (s1[3] << 23);
-}
-
-__device__ __forceinline__ int pair_index(int i, int j, int n) {  // i < j, the nested-loop order of :214-215
-  return i * n - i * (i + 1) / 2 + (j - i - 1);
-}
-
-// BS = samples per block: a work unit covers BS x BS pairs.  2: twelve 16-byte reads per 128 vector instructions
-// (1.5 B per instruction) — right for few samples, where only small blocks give every thread work; 4: twenty-four
-// reads per 512 instructions (0.75 B per instruction), 96 + 32 registers of planes and counters.
-template <int BS>
-__global__ __launch_bounds__(kPairThreads, BS == 2 ? 4 : 3) void abn_pairwise_bits_kernel(const PairArgs a) {
-  extern __shared__ __align__(16) uint32_t psm[];
-  const int tid = threadIdx.x;
-  const int n = a.n, WT = a.WT;
-  const int BP = BS * WT + 4;                // words per sample block (BS rows + pad)
-  const size_t PS = (size_t)a.nb * BP;       // words per plane
-  uint32_t* P1 = psm;
-  unsigned long long* red = reinterpret_cast<unsigned long long*>(psm + ((3 * PS + 1) & ~(size_t)1));  // [npairs]: both << 32 | diff
-  const size_t total = (size_t)n * (size_t)a.L;
-  const int wshift = 31 - __builtin_clz((unsigned)WT);
-  const int wslice = WT / a.S;               // words per slice (a multiple of 4)
-  auto row_off = [&](int r) { return (size_t)(r / BS) * BP + (size_t)(r % BS) * WT; };
-
-  if (a.red_in_lds)
-    for (int k = tid; k < a.npairs; k += kPairThreads) red[k] = 0ull;
-
-  int flush_no = 0;
-  auto flush_red = [&]() {  // LDS sums -> a row of this workgroup's own (one per flush), still packed both << 32 | diff:
-    __syncthreads();        // half the bytes of two 64-bit sums, here and in the reduce kernel
-    if (a.red_in_lds) {
-      unsigned long long* row = a.partial + ((size_t)flush_no * gridDim.x + blockIdx.x) * (size_t)a.npairs;
-      for (int k = tid; k < a.npairs; k += kPairThreads) {
-        row[k] = red[k];
-        red[k] = 0ull;
-      }
-      ++flush_no;
-    }
-    __syncthreads();
-  };
-
-  long long since_flush = 0;  // sites a per-pair sum may have seen since it was last cleared
-  for (long long t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
-    const long long s0 = t * (long long)(32 * WT);
-    __syncthreads();  // the previous tile has been consumed
-    // ---- stage
-    for (int task = tid; task < (a.dbg == 2 ? 0 : n * WT); task += kPairThreads) {
-      const int smp = task >> wshift, w = task & (WT - 1);
-      const long long site = s0 + 32ll * w;
-      const long long left = a.L - site;
-      const int valid = left < 32 ? (int)(left < 0 ? 0 : left) : 32;
-      const size_t off = (size_t)smp * (size_t)a.L + (size_t)site;
-      const PairRaw raw = pair_load(a.codes, total, off, valid);
-      uint32_t t1, t2, vv;
-      pair_convert(raw, a.codes, off, valid, t1, t2, vv);
-      uint32_t* dst = P1 + row_off(smp) + w;
-      dst[0] = t1;
-      dst[PS] = t2;
-      dst[2 * PS] = vv;
-    }
-    // the missing samples of the last block read as "no valid site"
-    for (int k = tid; k < (a.nb * BS - n) * WT; k += kPairThreads) P1[2 * PS + row_off(n + k / WT) + (k & (WT - 1))] = 0u;
-    __syncthreads();
-    // ---- pairs
-    for (int unit = tid; unit < (a.dbg == 1 ? 0 : a.units); unit += kPairThreads) {
-      const int item = unit % a.items, slice = unit / a.items;
-      const uint32_t ij = a.item_tab[item];
-      const int i0 = (int)(ij & 0xffffu), j0 = (int)(ij >> 16);
-      const uint32_t* ri = P1 + row_off(i0);     // the BS rows of a block are WT words apart
-      const uint32_t* rj = P1 + row_off(j0);
-      uint32_t d[BS * BS], c[BS * BS];
-#pragma unroll
-      for (int q = 0; q < BS * BS; ++q) d[q] = c[q] = 0u;
-      const int w0 = slice * wslice;
-      for (int w = w0; w < w0 + wslice; w += 4) {
-        u32x4_lds t1[2 * BS], t2[2 * BS], vv[2 * BS];
-#pragma unroll
-        for (int q = 0; q < BS; ++q) {
-          t1[q] = *reinterpret_cast<const u32x4_lds*>(ri + q * WT + w);
-          t2[q] = *reinterpret_cast<const u32x4_lds*>(ri + PS + q * WT + w);
-          vv[q] = *reinterpret_cast<const u32x4_lds*>(ri + 2 * PS + q * WT + w);
-          t1[BS + q] = *reinterpret_cast<const u32x4_lds*>(rj + q * WT + w);
-          t2[BS + q] = *reinterpret_cast<const u32x4_lds*>(rj + PS + q * WT + w);
-          vv[BS + q] = *reinterpret_cast<const u32x4_lds*>(rj + 2 * PS + q * WT + w);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-          for (int pi = 0; pi < BS; ++pi) {
-#pragma unroll
-            for (int pj = 0; pj < BS; ++pj) {
-              const uint32_t b = vv[pi][e] & vv[BS + pj][e];
-              const int q = BS * pi + pj;
-              d[q] += (uint32_t)__builtin_popcount((t1[pi][e] ^ t1[BS + pj][e]) & b);
-              d[q] += (uint32_t)__builtin_popcount((t2[pi][e] ^ t2[BS + pj][e]) & b);
-              c[q] += (uint32_t)__builtin_popcount(b);
-            }
-          }
-        }
-      }
-      // the pairs (i0 + pi, j0 + pj); p(i + 1, j) = p(i, j) + n - i - 2
-      int prow = pair_index(i0, j0, n);
-#pragma unroll
-      for (int pi = 0; pi < BS; ++pi) {
-#pragma unroll
-        for (int pj = 0; pj < BS; ++pj) {
-          const int q = BS * pi + pj, i = i0 + pi, j = j0 + pj;
-          if (i < j && j < n && (d[q] | c[q])) {  // i >= j (diagonal blocks) or a missing sample: not a pair
-            const unsigned long long v = ((unsigned long long)c[q] << 32) | d[q];
-            if (a.red_in_lds) {
-              atomicAdd(&red[prow + pj], v);
-            } else {
-              atomicAdd(&a.partial[2 * (prow + pj)], (unsigned long long)d[q]);
-              atomicAdd(&a.partial[2 * (prow + pj) + 1], (unsigned long long)c[q]);
-            }
-          }
-        }
-        prow += n - (i0 + pi) - 2;
-      }
-    }
-    since_flush += 32ll * WT;
-    if (a.red_in_lds && since_flush > (1ll << 30)) {  // diff <= 2 per site: stay far below 2^32
-      flush_red();
-      since_flush = 0;
-    }
-  }
-  flush_red();
-}
-
-// partial rows -> diff[p], both[p], dvalue[p] = diff / (2 both) in f64 (:257; 0/0 = NaN like the reference); any of
-// the three may be null.  A workgroup owns 16 columns (8 pairs): 64 row groups of 16 threads sum their rows (eight
-// loads in flight per thread), LDS combines the groups.  No atomics.  (Narrow column blocks on purpose: 1225 pairs are
-// 154 workgroups; with 64 columns each the 39 workgroups of that shape left most of the chip idle.)
-// PACKED (per-workgroup rows from LDS sums): partial[rows][npairs], one word both << 32 | diff per pair — a workgroup owns
-// 8 pairs, thread (pair, half) sums one 32-bit half of its column into 64 bits.  Else (global atomics, one row):
-// partial[rows][2 * npairs] (diff, both).  Same thread layout: 16 "columns" x 64 row groups.
-constexpr int kPairReduceCols = 16, kPairReduceGroups = 64;
-template <bool PACKED>
-__global__ __launch_bounds__(kPairReduceCols * kPairReduceGroups) void abn_pairwise_reduce_kernel(
-    const unsigned long long* partial, int rows, int npairs, unsigned long long* diff, unsigned long long* both,
-    double* dvalue) {
-  __shared__ unsigned long long part[kPairReduceGroups][kPairReduceCols];
-  const int cx = threadIdx.x & (kPairReduceCols - 1), g = threadIdx.x / kPairReduceCols;
-  const int c = blockIdx.x * kPairReduceCols + cx;   // column 2 p (diff) / 2 p + 1 (both) of pair p
-  const int cols = 2 * npairs;
-  unsigned long long acc = 0;
-  if (c < cols) {
-    if constexpr (PACKED) {
-      const int sh = (cx & 1) ? 32 : 0;
-#pragma unroll 8
-      for (int r = g; r < rows; r += kPairReduceGroups) acc += (partial[(size_t)r * (size_t)npairs + (c >> 1)] >> sh) & 0xffffffffull;
-    } else {
-#pragma unroll 8
-      for (int r = g; r < rows; r += kPairReduceGroups) acc += partial[(size_t)r * (size_t)cols + c];
-    }
-  }
-  part[g][cx] = acc;
-  __syncthreads();
-  // fold the row groups: 64 -> 8 rows in parallel, the last eight by the writing thread
-  for (int half = kPairReduceGroups / 2; half >= 8; half >>= 1) {
-    if (g < half) part[g][cx] += part[g + half][cx];
-    __syncthreads();
-  }
-  if (g == 0 && c < cols && (cx & 1) == 0) {
-    unsigned long long d = 0, cc = 0;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      d += part[k][cx];
-      cc += part[k][cx + 1];
-    }
-    const int p = c >> 1;
-    if (diff) diff[p] = d;
-    if (both) both[p] = cc;
-    if (dvalue) dvalue[p] = (double)d / (2.0 * (double)cc);
-  }
-}
-
 // src/boot_model.rs:86-91 for a batch of fitted vectors (abn_bootstrap_rows)
 __global__ __launch_bounds__(256) void abn_rows_kernel(const double* best, long long n, double* raw) {
   for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {

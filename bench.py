@@ -279,7 +279,7 @@ def pairwise_bench(A, ctx, shapes=((15, 4_000_000), (15, 32_000_000), (50, 32_00
                     "code_bytes": n * L, "achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
                     "site_pairs_per_s": npairs * L / (avg * 1e-3), "sane": ok})
         del codes
-    return {"kernel": "abn_pairwise_bits_kernel (+ reduce, finish)", "bound": "hbm", "unit": "GB/s",
+    return {"kernel": "abn_pairwise_mx_kernel (v_mfma_i32_16x16x64_i8 Gram products) + abn_pairwise_reduce_tiles_kernel", "bound": "hbm", "unit": "GB/s",
             "what": "n*L code bytes (one pass) / HIP-event time of the call's kernels, inputs resident in HBM",
             "shapes": out}
 

@@ -31,7 +31,7 @@ out = sys.argv[1]
 f = glob.glob(out + "/pmc_fetch/*/*_counter_collection.csv")[0]
 d = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if "pairwise_bits" in r["Kernel_Name"]:
+    if "pairwise_mx" in r["Kernel_Name"]:
         d[r["Kernel_Name"][:50]].append(float(r["Counter_Value"]))
 for k, v in d.items():
     a = sum(v) / len(v)

@@ -51,7 +51,8 @@ def test_gpu_pairwise_bundled_methylomes(abn, gpu_ctx, oracle, golden):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,L", [(2, 1), (2, 5), (3, 2047), (15, 2048), (15, 2049), (7, 100003), (70, 4100),
-                                 (130, 1500)])
+                                 (130, 1500), (16, 64), (17, 129), (33, 4097), (48, 1000), (50, 20011), (64, 5000),
+                                 (65, 700), (100, 3001), (129, 1031), (200, 515)])
 def test_gpu_pairwise_random(abn, gpu_ctx, oracle, n, L):
     rng = np.random.default_rng(n * 1000 + L)
     status = rng.integers(0, 3, size=(n, L), dtype=np.uint8)
@@ -66,18 +67,39 @@ def test_gpu_pairwise_random(abn, gpu_ctx, oracle, n, L):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,L", [(1100, 700), (2048, 300)])
+@pytest.mark.parametrize("n,L", [(1100, 700), (2048, 300), (4096, 130)])
 def test_gpu_pairwise_many_samples(abn, gpu_ctx, oracle, n, L):
-    """more samples than one 64 KiB tile holds (the launch opts in to the CU's 160 KiB of LDS; the per-pair
-    sums go through global atomics: 2 M pairs)"""
+    """The sample axis is tiled in groups of 64 (DMatrix::from has no limit on the number of samples, src/pedigree.rs:210-261;
+    rounds 2-3 refused more than one LDS tile of ~2700 samples): 4096 samples are 64 groups, 2080 pairs of groups."""
     rng = np.random.default_rng(n + L)
     status = rng.integers(0, 3, size=(n, L), dtype=np.uint8)
     pmax = rng.uniform(0.95, 1.0, size=(n, L))
     diff, both, dval = gpu_ctx.pairwise_divergence(_codes(status, pmax, 0.99))
     wd, wb, wv = oracle.pairwise_divergence(status, pmax, 0.99)
     assert np.array_equal(diff, wd) and np.array_equal(both, wb) and np.array_equal(dval, wv, equal_nan=True)
-    with pytest.raises(abn.AbnError):
-        gpu_ctx.pairwise_divergence(np.zeros((3000, 8), dtype=np.uint8))     # beyond one LDS tile: reported, not wrong
+
+
+@pytest.mark.gpu
+def test_gpu_pairwise_every_state_pair_and_operand_order(abn, gpu_ctx, oracle):
+    """Exact-integer check of the matrix-instruction form: every (state_a, state_b) combination of {U, I, M, filtered U/I/M}
+    in known counts, on samples in DIFFERENT 16-sample blocks and groups (an asymmetric layout: a transposed tile or a
+    swapped table half would show)."""
+    n, reps = 150, 37
+    states = np.array([0, 1, 2, 0x80, 0x81, 0x82], dtype=np.uint8)
+    rng = np.random.default_rng(7)
+    codes = states[rng.integers(0, 6, size=(n, 36 * reps))]
+    a, b = 3, 141                                       # samples of different groups: all 36 combinations, (k+1) times each
+    cols = []
+    for ia, sa in enumerate(states):
+        for ib, sb in enumerate(states):
+            cols += [(sa, sb)] * ((6 * ia + ib) % 5 + 1)
+    cols = np.array(cols, dtype=np.uint8)
+    codes[a, : len(cols)] = cols[:, 0]
+    codes[b, : len(cols)] = cols[:, 1]
+    diff, both, dval = gpu_ctx.pairwise_divergence(codes)
+    status, pmax = codes & 3, np.where(codes & 0x80, 0.5, 1.0)
+    wd, wb, wv = oracle.pairwise_divergence(status, pmax, 0.99)
+    assert np.array_equal(diff, wd) and np.array_equal(both, wb) and np.array_equal(dval, wv, equal_nan=True)
 
 
 @pytest.mark.gpu
