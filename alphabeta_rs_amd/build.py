@@ -14,7 +14,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libabneutral_hip.so"
 SOURCES = [CSRC / "abn_api.hip", CSRC / "abn_multi.hip"]
-DEPS = [CSRC / "abn_device.hpp", CSRC / "abn_philox.h", PKG.parent / "include" / "abneutral.h"]
+DEPS = [CSRC / "abn_device.hpp", CSRC / "abn_pairwise_mx.hpp", CSRC / "abn_philox.h", PKG.parent / "include" / "abneutral.h"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
@@ -50,6 +50,23 @@ def build_hip(force: bool = False, verbose: bool = False) -> Path:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True, cwd=str(PKG))
     return LIB
+
+
+KNOBS_LIB = PKG.parent / "build" / "libabn_knobs.so"
+
+
+def build_knobs(force: bool = False, verbose: bool = False) -> Path:
+    """The same sources with -DABN_MEASUREMENT_KNOBS (environment switches for the sweeps under scripts/ and the fault
+    injection of tests/test_gpu_parity.py::test_lost_fifo_entry_is_an_error_at_sync).  Never loaded by the product: the
+    package takes it only through ABNEUTRAL_HIP_LIB."""
+    if not force and KNOBS_LIB.exists() and all(p.stat().st_mtime <= KNOBS_LIB.stat().st_mtime for p in SOURCES + DEPS):
+        return KNOBS_LIB
+    KNOBS_LIB.parent.mkdir(exist_ok=True)
+    cmd = [hipcc_path(), *HIPCC_FLAGS, "-DABN_MEASUREMENT_KNOBS", "-o", str(KNOBS_LIB), *map(str, SOURCES)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=str(PKG))
+    return KNOBS_LIB
 
 
 HOST = PKG / "host"

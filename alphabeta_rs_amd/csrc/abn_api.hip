@@ -253,15 +253,15 @@ static int pick_lanes(int n, int requested, int chain_stride) {
   while (g < 64 && (size_t)(kWave / g) * per_chain > kLdsTargetPerBlock) g *= 2;
   return g;
 }
-static bool fit_streams(int n, int chain_stride, int lanes);
-static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree);
+static bool fit_streams(int n, int chain_stride, int lanes, int strict = 0);
+static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree, int strict);
 // The residual reduction tree (FitArgs::tree; abn_fit_info.lanes).  Auto (lanes_per_chain == 0) and the pedigree
 // LDS-resident: the canonical 64-accumulator tree, which every kernel — packed, one wavefront per chain, four
 // wavefronts per chain — runs at its native cost.  Streamed pedigrees and explicit lane counts: one accumulator per
 // lane of the packed kernel.
 static int pick_tree(int n, int requested, int chain_stride, int lanes, int strict = 0) {
   if (strict) return 1;  // serial row order (abn_options.strict_order): no tree
-  if (requested != 0 || fit_streams(n, chain_stride, lanes)) return lanes;
+  if (requested != 0 || fit_streams(n, chain_stride, lanes, strict)) return lanes;
   return kTreeCanon;
 }
 static int pick_rmax(int n, int lanes) {
@@ -370,6 +370,9 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, int* kin
     if (const char* e = getenv("ABN_QUANTUM_ENV")) {
       if (a.quantum > 0) a.quantum = std::max(16, atoi(e));
     }
+    // tests/test_gpu_parity.py::test_lost_fifo_entry_is_an_error_at_sync: the first parked chain of FIFO shard 0 is never
+    // published — the launch must end (bounded spin), and every way of taking results must report ABN_ERR_HIP
+    if (const char* e = getenv("ABN_DROP_FIFO_ENTRY")) a.drop_entry = atoi(e);
   }
 #endif
   if (refill && a.slice_status) HIPCHK(c, hipMemsetAsync(a.slice_status, 0, 2 * sizeof(unsigned), st));
@@ -393,10 +396,12 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, int* kin
   return ABN_OK;
 }
 
-// true when launch_fit will use the stream variant for this pedigree / lane count
-static bool fit_streams(int n, int chain_stride, int lanes) {
+// true when launch_fit will use the stream variant for this pedigree / lane count.  Strict order keeps the rows' terms in
+// LDS next to the observations (N more doubles per chain): the same footprint launch_fit computes, so that what a plan
+// decides (and validates) at abn_plan_create is what runs.
+static bool fit_streams(int n, int chain_stride, int lanes, int strict) {
   if (pick_rmax(n, lanes) == 0) return true;
-  const int np = ((n + 1) & ~1) + n / 2 + 2;  // observations + triple list (K <= n)
+  const int np = ((n + 1) & ~1) + n / 2 + 2 + (strict ? ((n + 1) & ~1) : 0);  // observations + triple list (K <= n) (+ terms)
   return (size_t)(kWave / lanes) * (size_t)(chain_stride + np) * sizeof(double) > kLdsResidentMax;
 }
 
@@ -410,12 +415,13 @@ static long long spec_max_chains(int n_rows) {
   return pick_rmax(n_rows, kWave) <= 2 ? kPhaseASpecMax : kPhaseASpecMax * 2 / 3;
 }
 
-// a wavefront per chain runs the canonical tree whenever the pedigree is LDS-resident at 64 lanes per chain
-static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree) {
-  if (tree != kTreeCanon && tree != 1) return tree == kWave;
+// a wavefront per chain runs the canonical tree (or, strict order, the serial sum) whenever the pedigree is LDS-resident
+// at 64 lanes per chain; an explicit lanes_per_chain tree only when it IS 64 lanes
+static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree, int strict) {
+  if (!strict && tree != kTreeCanon) return tree == kWave;
   const int rmax = pick_rmax(n_rows, kWave);
   if (rmax <= 0) return false;
-  const int np = ((n_rows + 1) & ~1) + n_rows / 2 + 2 + (tree == 1 ? ((n_rows + 1) & ~1) : 0);  // strict order: + the terms
+  const int np = ((n_rows + 1) & ~1) + n_rows / 2 + 2 + (strict ? ((n_rows + 1) & ~1) : 0);  // strict order: + the terms
   return (size_t)(chain_stride + np) * sizeof(double) <= kLdsResidentMax;
 }
 
@@ -423,7 +429,7 @@ static bool spec_applicable(const FitArgs& a) {
   if (a.dmode == 2) return false;  // resident observations only (starts, or bootstraps gathered through the index row)
   const int rmax = pick_rmax(a.N, kWave);
   if (rmax == 0 || rmax > 8) return false;  // 16 rows per lane: the plain resident kernel
-  if (!tree_on_wave_ok(a.N, a.chain_stride, a.tree)) return false;
+  if (!tree_on_wave_ok(a.N, a.chain_stride, a.tree, a.strict)) return false;
   const int np = ((a.N + 1) & ~1) * (a.strict ? 2 : 1);   // observations (+ strict order: the rows' terms)
   return (3 * (size_t)(a.chain_stride + np) + kSpecCommDoubles) * sizeof(double) <= kLdsResidentMax;
 }
@@ -479,6 +485,20 @@ static abn_options resolve(const abn_options* o) {
   return d;
 }
 
+// The summation order of a pedigree (abn_options.strict_order: -1 tree, 0 auto, 1 serial) resolved to 0 / 1.  Auto sums
+// pedigrees of up to kSerialSumMaxRows rows SERIALLY in row order — the reference's `square_sum += ...`
+// (src/structs.rs:206-213), where a serial sum costs nothing measurable and the bundled data/ pedigree (6 rows: the
+// north star's parity target, on which `weight` is not identified and a last-ulp difference in a cost can move a
+// bootstrap row by O(1)) is then bit-equal to the reference order by DEFAULT.  Like the tree, a function of the pedigree
+// (and the options) alone: never of the launch.  An explicit lanes_per_chain keeps its per-lane tree.
+constexpr int kSerialSumMaxRows = 16;
+static abn_options resolve_for(const abn_options* o, int n_rows) {
+  abn_options d = resolve(o);
+  if (d.strict_order == 0 && d.lanes_per_chain == 0 && n_rows <= kSerialSumMaxRows) d.strict_order = 1;
+  else if (d.strict_order < 0) d.strict_order = 0;
+  return d;
+}
+
 // iteration budgets must leave room for the 32-bit evaluation counters (at most 2 evaluations per iteration plus the
 // 4 of a shrink); lane counts are 0 (auto) or a power of two up to the wavefront; the tolerance must compare
 static const char* options_error(const abn_options& o) {
@@ -490,6 +510,7 @@ static const char* options_error(const abn_options& o) {
   if (o.sd_tolerance != o.sd_tolerance) return "sd_tolerance is NaN";
   if (o.stream_mode < 0 || o.stream_mode > 1) return "stream_mode must be 0 or 1";
   if (o.window_groups < 0) return "window_groups must be >= 0";
+  if (o.strict_order < -1 || o.strict_order > 1) return "strict_order must be -1 (tree), 0 (auto) or 1 (serial)";
   return nullptr;
 }
 
@@ -497,11 +518,11 @@ static const char* options_error(const abn_options& o) {
 // the topology alone — no device, no launch size.
 extern "C" int abn_reduction_tree(const abn_options* opts, const double* generations, int32_t n_rows, int32_t* tree) {
   if (!generations || n_rows <= 0 || !tree) return ABN_ERR_INVALID_ARG;
-  const abn_options o = resolve(opts);
-  if (const char* oe = options_error(o)) {
+  if (const char* oe = options_error(resolve(opts))) {
     (void)oe;
     return ABN_ERR_INVALID_ARG;
   }
+  const abn_options o = resolve_for(opts, n_rows);
   Topology t;
   const int rc = build_topology(generations, n_rows, 3, t);
   if (rc) return rc;
@@ -659,7 +680,8 @@ extern "C" int abn_cost_batch(abn_ctx* c, const abn_options* opts, const double*
   if (!pedigree || n_rows <= 0 || !candidates || m < 0 || !cost) return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
   if (idx && (!pred || !resid || n_boot_rows <= 0)) return set_err(c, ABN_ERR_INVALID_ARG, "bootstrap inputs");
   if (m == 0) return ABN_OK;
-  const abn_options o = resolve(opts);
+  if (const char* oe = options_error(resolve(opts))) return set_err(c, ABN_ERR_INVALID_ARG, oe);
+  const abn_options o = resolve_for(opts, n_rows);
   HIPCHK(c, hipSetDevice(c->device));
   PoolScope pool_scope(c);
   Topology t;
@@ -758,8 +780,8 @@ extern "C" int abn_fit_batch(abn_ctx* c, const abn_options* opts, const double* 
   if (!pedigree || n_rows <= 0 || !simplex0 || f < 0 || !best || max_iters < 0 || f > 0x7fffffff)
     return set_err(c, ABN_ERR_INVALID_ARG, "null/size");
   if (f == 0) return ABN_OK;
-  const abn_options o = resolve(opts);
-  if (const char* oe = options_error(o)) return set_err(c, ABN_ERR_INVALID_ARG, oe);
+  if (const char* oe = options_error(resolve(opts))) return set_err(c, ABN_ERR_INVALID_ARG, oe);
+  const abn_options o = resolve_for(opts, n_rows);
   if (max_iters < 0 || max_iters > (1 << 28)) return set_err(c, ABN_ERR_INVALID_ARG, "max_iters must be in 0 .. 2^28");
   HIPCHK(c, hipSetDevice(c->device));
   PoolScope pool_scope(c);
@@ -902,7 +924,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   abn_plan* p = new (std::nothrow) abn_plan();
   if (!p) return ABN_ERR_HIP;
   p->ctx = c;
-  p->opt = resolve(opts);
+  p->opt = resolve_for(opts, n_rows);  // strict_order resolved to 0 / 1 for this pedigree
   p->N = n_rows;
   p->W = n_windows;
   p->S = n_starts;
@@ -925,9 +947,13 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   // The reduction tree stays the pedigree's (p->tree) whichever kernel runs: results do not depend on the size of
   // the launch, hence not on how a job is sharded over GPUs.
   if (p->opt.lanes_per_chain == 0 && (long long)n_windows * n_starts <= kPhaseAWideMax &&
-      tree_on_wave_ok(n_rows, p->topo.chain_stride, p->tree))
+      tree_on_wave_ok(n_rows, p->topo.chain_stride, p->tree, p->opt.strict_order))
     p->lanes_a = 64;
-  if ((size_t)(kWave / p->lanes) * p->topo.chain_stride * sizeof(double) > (p->lanes == kWave ? kMaxDynLds : kDefaultDynLds) ||
+  // the footprint launch_fit will ask for when the pedigree is streamed (resident launches stay below kLdsResidentMax by
+  // construction): the scratch of the workgroup's chains, plus one chunk of terms per chain in strict order — validated
+  // here, not at the first run
+  const size_t stream_stride = (size_t)p->topo.chain_stride + (p->opt.strict_order ? (size_t)kStrictRowsPerLane * p->lanes : 0);
+  if ((size_t)(kWave / p->lanes) * stream_stride * sizeof(double) > (p->lanes == kWave ? kMaxDynLds : kDefaultDynLds) ||
       ((size_t)p->topo.chain_stride + kSelChunk) * sizeof(double) > kMaxDynLds) {
     delete p;
     return set_err(c, ABN_ERR_INVALID_ARG, "pedigree needs more LDS per workgroup than supported (T or K too large)");
@@ -983,7 +1009,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
       PALLOC(slice_buf, (size_t)kParkShards * ((size_t)kParkHeaderInts + (size_t)p->slice_cap));
     }
   }
-  p->stream_b = n_boot > 0 && fit_streams(n_rows, p->topo.chain_stride, p->lanes) && p->opt.stream_mode == 0;
+  p->stream_b = n_boot > 0 && fit_streams(n_rows, p->topo.chain_stride, p->lanes, p->opt.strict_order) && p->opt.stream_mode == 0;
   if (p->stream_b) PALLOC(dstar, W * B * N);
 #undef PALLOC
   p->raw = p->raw_own.p;
@@ -1132,7 +1158,7 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   int lanes_a = p->lanes_a;
 #ifdef ABN_MEASUREMENT_KNOBS  // ABN_PHASE_A_KERNEL = spec | wide | packed  (scripts/phase_a_sweep.py)
   if (const char* e = getenv("ABN_PHASE_A_KERNEL")) {
-    const bool can_wide = p->opt.lanes_per_chain == 0 && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree);
+    const bool can_wide = p->opt.lanes_per_chain == 0 && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree, p->opt.strict_order);
     if (!strcmp(e, "spec")) spec = can_wide && spec_applicable(a);
     if (!strcmp(e, "wide")) { spec = false; if (can_wide) lanes_a = kWave; }
     if (!strcmp(e, "packed")) { spec = false; lanes_a = p->lanes; }
@@ -1250,11 +1276,11 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   // several chains into one (scripts/b_kernel_sweep.py, C3 topology: 2000 bootstraps 1.36 ms against 1.74 ms packed and
   // 1.81 ms speculative; 4000: 1.99 against 1.75; bundled 6-row pedigree, 8 lanes: 2000 bootstraps 1.98 against 1.90)
   if (!spec && a.dmode == 1 && p->opt.lanes_per_chain == 0 && p->lanes < kWave &&
-      (long long)p->W * p->B <= 192LL * p->lanes && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree))
+      (long long)p->W * p->B <= 192LL * p->lanes && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree, p->opt.strict_order))
     lanes_b = kWave;
 #ifdef ABN_MEASUREMENT_KNOBS  // ABN_PHASE_B_KERNEL = spec | wide | packed
   if (const char* e = getenv("ABN_PHASE_B_KERNEL")) {
-    const bool can_wide = a.dmode == 1 && p->opt.lanes_per_chain == 0 && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree);
+    const bool can_wide = a.dmode == 1 && p->opt.lanes_per_chain == 0 && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree, p->opt.strict_order);
     if (!strcmp(e, "spec")) spec = can_wide && spec_applicable(a);
     if (!strcmp(e, "wide")) { spec = false; if (can_wide) lanes_b = kWave; }
     if (!strcmp(e, "packed")) spec = false;
@@ -1356,10 +1382,31 @@ extern "C" int abn_plan_run(abn_plan* p) {
   return ABN_OK;
 }
 
+// A persistent launch must have finished every chain it was given: a lost FIFO entry or a chain that was parked and never
+// taken up again would otherwise leave stale (or, in a bound buffer, uninitialised) rows in the tables.  Synchronises the
+// stream.  Every entry point a caller can take results from runs this — abn_plan_sync (bind_raw / raw_device_ptr users:
+// the torch.distributed shard runner), abn_plan_failed_windows, abn_plan_download, and through them abn_multi_sync /
+// abn_multi_download.
+static int verify_persistent(abn_plan* p) {
+  abn_ctx* c = p->ctx;
+  HIPCHK(c, hipSetDevice(c->device));
+  unsigned sl[4] = {0, 0, 0, 0};
+  const bool check = p->persist_expected[0] > 0 || p->persist_expected[1] > 0;
+  if (check) HIPCHK(c, hipMemcpyAsync(sl, p->slice_status.p, sizeof sl, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int ph = 0; ph < 2 && check; ++ph) {
+    if (p->persist_expected[ph] <= 0) continue;
+    if (sl[2 * ph] != 0 || (long long)sl[2 * ph + 1] != p->persist_expected[ph])
+      return set_err(c, ABN_ERR_HIP, std::string("persistent fit launch of phase ") + (ph ? "B" : "A") + " finished " +
+                                         std::to_string(sl[2 * ph + 1]) + " of " + std::to_string(p->persist_expected[ph]) +
+                                         " chains (error word " + std::to_string(sl[2 * ph]) + "): results are incomplete");
+  }
+  return ABN_OK;
+}
+
 extern "C" int abn_plan_sync(abn_plan* p) {
   if (!p) return ABN_ERR_INVALID_ARG;
-  HIPCHK(p->ctx, hipStreamSynchronize(p->ctx->stream));
-  return ABN_OK;
+  return verify_persistent(p);
 }
 
 extern "C" int abn_plan_kernel_ms(abn_plan* p, double* ms3) {
@@ -1411,19 +1458,7 @@ extern "C" int abn_plan_download(abn_plan* p, double* models, double* pred, doub
     bs.resize(W);
     HIPCHK(c, hipMemcpyAsync(bs.data(), p->best_start.p, p->best_start.bytes(), hipMemcpyDeviceToHost, s));
   }
-  unsigned sl[4] = {0, 0, 0, 0};
-  const bool check_persist = p->persist_expected[0] > 0 || p->persist_expected[1] > 0;
-  if (check_persist) HIPCHK(c, hipMemcpyAsync(sl, p->slice_status.p, sizeof sl, hipMemcpyDeviceToHost, s));
-  HIPCHK(c, hipStreamSynchronize(s));
-  // a persistent launch must have finished every chain it was given: a lost FIFO entry or a chain that was parked and
-  // never taken up again would otherwise leave stale rows in the tables
-  for (int ph = 0; ph < 2 && check_persist; ++ph) {
-    if (p->persist_expected[ph] <= 0) continue;
-    if (sl[2 * ph] != 0 || (long long)sl[2 * ph + 1] != p->persist_expected[ph])
-      return set_err(c, ABN_ERR_HIP, std::string("persistent fit launch of phase ") + (ph ? "B" : "A") + " finished " +
-                                         std::to_string(sl[2 * ph + 1]) + " of " + std::to_string(p->persist_expected[ph]) +
-                                         " chains (error word " + std::to_string(sl[2 * ph]) + "): results are incomplete");
-  }
+  if (int rc = verify_persistent(p)) return rc;  // synchronises the stream
   if (best_start) {
     if (p->ran_a) std::copy(bs.begin(), bs.end(), best_start);
     else std::fill(best_start, best_start + W, 0);  // model uploaded by the caller (abn_boot_model_run)
@@ -1438,11 +1473,11 @@ extern "C" int abn_plan_failed_windows(abn_plan* p, int32_t* n_failed) {
   if (!p || !n_failed) return ABN_ERR_INVALID_ARG;
   abn_ctx* c = p->ctx;
   *n_failed = 0;
-  if (!p->ran_a) return ABN_OK;
+  if (!p->ran_a) return verify_persistent(p);
   HIPCHK(c, hipSetDevice(c->device));
   std::vector<int32_t> bs((size_t)p->W);
   HIPCHK(c, hipMemcpyAsync(bs.data(), p->best_start.p, p->best_start.bytes(), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (int rc = verify_persistent(p)) return rc;  // synchronises the stream
   for (int32_t b : bs) *n_failed += b < 0 ? 1 : 0;
   return ABN_OK;
 }

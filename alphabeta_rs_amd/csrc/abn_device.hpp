@@ -143,6 +143,9 @@ struct FitArgs {
   // thresholds prio_t[] that the evaluations of its OLDEST running chain have passed (mode 1), or 3 minus that (mode 2).
   int prio_mode;
   int prio_t[3];
+#ifdef ABN_MEASUREMENT_KNOBS
+  int drop_entry;        // fault injection for the tests: FIFO shard 0 never publishes its first entry
+#endif
   double sd_tol;
   double gap_tol;        // 64 * sd_tol, precomputed on the host so that it stays a scalar (kernarg) operand
   // outputs (fit order)
@@ -596,6 +599,34 @@ __device__ __forceinline__ double serial_sum_lds(const double* t, int n, double 
   return acc;
 }
 
+// The same sum for a pedigree of at most 16 rows held one row per lane (lane i: row i's term, +0.0 in the lanes past the
+// last row) by a wavefront that serves ONE chain: 0.0 + t[0] + t[1] + ... in row order through v_readlane — no LDS round
+// trip on the latency path (the bundled six-row pedigree is summed this way by default: abn_options.strict_order = 0).
+// The +0.0 terms past row n - 1 change no bit (no partial sum is -0.0).
+__device__ __forceinline__ double serial_sum_lanes16(double term, int n) {
+  const int lo = __double2loint(term), hi = __double2hiint(term);
+  double acc = 0.0;
+  // Eight lane reads at constant lanes first (independent: they pipeline; read pair by pair into the same scalar registers
+  // they serialise with the additions), then the dependent additions, four per wavefront-uniform exit test.
+#pragma unroll
+  for (int base = 0; base < 16; base += 8) {
+    if (base >= n) break;
+    int l[8], h[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      l[j] = __builtin_amdgcn_readlane(lo, base + j);
+      h[j] = __builtin_amdgcn_readlane(hi, base + j);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = acc + __hiloint2double(h[j], l[j]);
+    if (base + 4 < n) {
+#pragma unroll
+      for (int j = 4; j < 8; ++j) acc = acc + __hiloint2double(h[j], l[j]);
+    }
+  }
+  return acc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // The fit kernel.  RMAX > 0 ("resident", needs N <= G*RMAX): the chain's observed divergences
 // (bootstrap: pred_i + resid[idx_i], gathered once per fit) are staged in LDS, each lane keeps its
@@ -764,9 +795,13 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
           x[q] = ((gl + G * (q0 + q)) < N) ? term : 0.0;     // x + 0.0 == x bit for bit (no sum is -0.0)
         }
         if constexpr (STRICT) {
+          if (G == kWave && RR == 1 && N <= 16) {            // one chain per wavefront, one row per lane: lane reads
+            acc = serial_sum_lanes16(x[0], N);
+          } else {
 #pragma unroll
-          for (int q = 0; q < RC; ++q)
-            if ((gl + G * (q0 + q)) < N) term[gl + G * (q0 + q)] = x[q];
+            for (int q = 0; q < RC; ++q)
+              if ((gl + G * (q0 + q)) < N) term[gl + G * (q0 + q)] = x[q];
+          }
         } else if (canon) {                                  // uniform: row gl + G q belongs to accumulator gl + G (q mod NA)
 #pragma unroll
           for (int q = 0; q < RC; ++q) av[(q0 + q) % NA] = av[(q0 + q) % NA] + x[q];
@@ -776,8 +811,10 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
         }
       }
       if constexpr (STRICT) {                                // `square_sum += ...` in row order, src/structs.rs:206-213
-        __syncthreads();
-        acc = serial_sum_lds(term, N, 0.0);
+        if (!(G == kWave && RR == 1 && N <= 16)) {
+          __syncthreads();
+          acc = serial_sum_lds(term, N, 0.0);
+        }
         summed = true;
       } else if (canon) {
         acc = tree64_finish<G>(av);                          // P5, the pedigree's tree
@@ -1538,6 +1575,9 @@ __global__ __launch_bounds__(kWave, ABN_REFILL_MIN_WAVES) void abn_fit_refill_ke
         if (__ballot(parking) != 0ull) asm volatile("s_waitcnt vmcnt(0) ; abn: parked state written through" ::: "memory");
         if (parking && gl == 0) {
           const unsigned pos = atomicAdd(pht + kParkTail, 1u);
+#ifdef ABN_MEASUREMENT_KNOBS
+          if (!(a.drop_entry != 0 && pos == 0 && (blockIdx.x & (kParkShards - 1)) == 0))
+#endif
           __hip_atomic_store(pk + pos, (int)chain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicAdd(reinterpret_cast<int*>(pht) + kParkAvail, 1);
         }
@@ -1753,16 +1793,21 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_ker
       tv[q] = in ? dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu] : 0.0;
     }
     if constexpr (STRICT) {   // `square_sum += ...` in row order, src/structs.rs:206-213
-      double* term = dobs + ((N + 1) & ~1);
+      if (RMAX == 1 && N <= 16) {   // one row per lane, at most 16 rows: the sum through lane reads (wavefront-uniform branch)
+        const double r = dv[0] - ic - tv[0];
+        acc = serial_sum_lanes16(gl < N ? r * r + pen : 0.0, N);
+      } else {
+        double* term = dobs + ((N + 1) & ~1);
 #pragma unroll
-      for (int q = 0; q < RMAX; ++q) {
-        if ((gl + G * q) < N) {
-          const double r = dv[q] - ic - tv[q];
-          term[gl + G * q] = r * r + pen;
+        for (int q = 0; q < RMAX; ++q) {
+          if ((gl + G * q) < N) {
+            const double r = dv[q] - ic - tv[q];
+            term[gl + G * q] = r * r + pen;
+          }
         }
+        wave_lds_fence();
+        acc = serial_sum_lds(term, N, 0.0);
       }
-      wave_lds_fence();
-      acc = serial_sum_lds(term, N, 0.0);
     } else {
 #pragma unroll
       for (int q = 0; q < RMAX; ++q) {

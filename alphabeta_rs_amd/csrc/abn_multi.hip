@@ -328,6 +328,11 @@ extern "C" int abn_multi_sync(abn_multi* m) {
     MHIP(m, hipSetDevice(m->dev[(size_t)i]));
     MHIP(m, hipStreamSynchronize(m->stream[(size_t)i]));
   }
+  // a persistent launch that lost a chain is an error here too, not only at the download (the gathered table may be read
+  // through abn_multi_raw_device_ptr)
+  for (int i = 0; i < m->n; ++i)
+    if (m->plan[(size_t)i])
+      if (int rc = abn_plan_sync(m->plan[(size_t)i])) return plan_fail(m, i, rc, "abn_plan_sync");
   return ABN_OK;
 }
 

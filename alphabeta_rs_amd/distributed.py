@@ -86,23 +86,36 @@ def run_sharded(compute_shard: Callable[[Shard], "np.ndarray"], n_windows: int, 
         local = torch.as_tensor(np.ascontiguousarray(local), dtype=torch.float64)
     if device is not None:
         local = local.to(device)
+    # What went wrong on this rank travels NEXT TO the gather, in a collective every rank enters: [windows without a finite
+    # start, 1 if the shard's run failed].  A rank that raised before the gather would leave the others waiting in the
+    # collective until its watchdog fires; so a runner records its failure (attributes `failed_windows`, `error`), still
+    # returns a table of the right shape, and every rank raises here together.
+    local_err = getattr(compute_shard, "error", None)
+    flags = torch.tensor([int(getattr(compute_shard, "failed_windows", 0)), 1 if local_err is not None else 0],
+                         dtype=torch.int64, device=local.device)
+    dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=group)
     full = gather_tables(local, n_windows, n_boot, group=group)
-    # A window without a finite start has NaN rows (abn_plan_download: ABN_ERR_NO_FINITE_FIT; the reference panics,
-    # src/ab_neutral.rs:28,100).  The verdict is taken from the GATHERED table, so every rank raises together: a rank
-    # that raised before the gather would leave the others waiting in the collective until its watchdog fires.
-    if n_windows * n_boot:
-        dead = torch.isnan(full[:, :, 0]).all(dim=1)
-        if bool(dead.any().item()):
-            from . import AbnError
+    from . import AbnError
 
-            ws = [int(w) for w in torch.nonzero(dead).flatten().tolist()]
-            raise AbnError(5, f"{len(ws)} window(s) have no finite start (NaN rows): {ws[:8]}{'...' if len(ws) > 8 else ''}")
+    if int(flags[1].item()):
+        raise AbnError(getattr(local_err, "status", 4),
+                       f"{int(flags[1].item())} rank(s) failed in their shard" + (f"; this rank: {local_err}" if local_err else ""))
+    # A window without a finite start has NaN rows (abn_plan_download: ABN_ERR_NO_FINITE_FIT; the reference panics,
+    # src/ab_neutral.rs:28,100).  Primary signal: the exchanged count; the NaN scan of the gathered table names the windows
+    # (and catches a runner that does not report).
+    dead = torch.isnan(full[:, :, 0]).all(dim=1) if n_windows * n_boot else torch.zeros(n_windows, dtype=torch.bool)
+    if int(flags[0].item()) or bool(dead.any().item()):
+        ws = [int(w) for w in torch.nonzero(dead).flatten().tolist()]
+        raise AbnError(5, f"{max(len(ws), int(flags[0].item()))} window(s) have no finite start (NaN rows): "
+                          f"{ws[:8]}{'...' if len(ws) > 8 else ''}")
     return full, shard
 
 
 def hip_shard_runner(ctx, generations, d_obs, p0uu, n_starts, options=None):
     """compute_shard for the MI355X path: one abn_plan per rank, bootstrap table written straight into a
-    torch tensor (no copy before the RCCL gather)."""
+    torch tensor (no copy before the RCCL gather).  The runner itself never raises an AbnError: it records it
+    (`run.error`, `run.failed_windows`) for run_sharded, which raises on every rank after the collectives; a caller that
+    uses the runner on its own must look at those two attributes."""
     import torch
 
     from . import Plan
@@ -115,15 +128,25 @@ def hip_shard_runner(ctx, generations, d_obs, p0uu, n_starts, options=None):
         raw = torch.empty((wn, shard.n_boot, 7), dtype=torch.float64, device=f"cuda:{ctx.device}")
         if wn == 0 or shard.n_boot == 0:
             return raw
-        plan = Plan(ctx, generations, wn, n_starts, shard.n_boot, window_offset=w0, boot_offset=shard.boot_offset,
-                    options=options)
-        plan.bind_raw(raw.data_ptr())
-        plan.set_windows(d_obs[w0:w0 + wn], p0uu[w0:w0 + wn])
-        plan.run()
-        plan.sync()
-        run.failed_windows = plan.failed_windows()   # local count, for logging; run_sharded raises on EVERY rank after
-        plan.close()                                  # the gather (the failed windows' rows are NaN)
+        from . import AbnError
+
+        plan = None
+        try:
+            plan = Plan(ctx, generations, wn, n_starts, shard.n_boot, window_offset=w0, boot_offset=shard.boot_offset,
+                        options=options)
+            plan.bind_raw(raw.data_ptr())
+            plan.set_windows(d_obs[w0:w0 + wn], p0uu[w0:w0 + wn])
+            plan.run()
+            plan.sync()                                   # ABN_ERR_HIP if a persistent launch lost a chain
+            run.failed_windows = plan.failed_windows()    # run_sharded exchanges the count and raises on EVERY rank
+        except AbnError as e:                             # (with bootstraps sharded every rank sees the same windows:
+            run.error = e                                 # the sum then counts them once per rank — it only has to be > 0)
+            raw.fill_(float("nan"))                       # the table still has its shape: the gather must be entered
+        finally:
+            if plan is not None:
+                plan.close()
         return raw
 
     run.failed_windows = 0
+    run.error = None
     return run

@@ -436,8 +436,8 @@ def single_process_main(args) -> None:
     os.dup2(2, 1)
     devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
     n = len(devices)
-    if args.devices is None and args.gpus != n:
-        raise SystemExit("--gpus and --devices disagree")
+    if args.devices and any(x == "--gpus" or x.startswith("--gpus=") for x in sys.argv) and args.gpus != n:   # both given explicitly: they must agree
+        raise SystemExit(f"--gpus {args.gpus} and --devices {args.devices} ({n} devices) disagree")
     A.load_library(build_if_missing=True)
     if A.device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the ABneutral path has no CPU fallback")
@@ -454,7 +454,7 @@ def single_process_main(args) -> None:
         label = f"C4: C3 topology, {W} windows x (10 starts + 1000 bootstraps), windows sharded over the devices"
     else:
         raise SystemExit("--single-process times the workloads c3, c4 and c4s")
-    opts = A.default_options(seed=seed, lanes_per_chain=args.lanes, strict_order=1 if args.strict_order else 0,
+    opts = A.default_options(seed=seed, lanes_per_chain=args.lanes, strict_order=1 if args.strict_order else (-1 if args.tree_order else 0),
                              no_fixed_point_skip=1 if args.execute_stuck_fits else 0)
     m = A.MultiPlan(devices, gens, W, S, B, options=opts)
     m.set_windows(D, p0)
@@ -524,6 +524,9 @@ def main():
     ap.add_argument("--execute-stuck-fits", action="store_true",
                     help="abn_options.no_fixed_point_skip = 1: execute the repeated iterations of fits that have reached "
                          "argmin's fixed point, as the reference does (same outputs; default: finish them at once)")
+    ap.add_argument("--tree-order", action="store_true",
+                    help="abn_options.strict_order = -1: the pedigree's reduction tree even for pedigrees of up to 16 rows "
+                         "(which the default sums serially, in the reference's order): A/B of what that default costs on C2")
     ap.add_argument("--strict-order", action="store_true",
                     help="abn_options.strict_order = 1: every cost sums its residuals serially in row order, as the "
                          "reference does (src/structs.rs:206-213); fits are then bit-equal to the oracle's lanes = 1. "
@@ -608,7 +611,7 @@ def main():
     N, Wr, S, B = wl["gens"].shape[0], wl["wr"], wl["S"], wl["B"]
     stream = torch.cuda.current_stream().cuda_stream
     ctx = A.Context(local_rank, stream=stream)
-    opts = A.default_options(seed=seed, lanes_per_chain=args.lanes, strict_order=1 if args.strict_order else 0,
+    opts = A.default_options(seed=seed, lanes_per_chain=args.lanes, strict_order=1 if args.strict_order else (-1 if args.tree_order else 0),
                              no_fixed_point_skip=1 if args.execute_stuck_fits else 0)
     by_boot = wl.get("shard") == "bootstraps"
     plan = A.Plan(ctx, wl["gens"], Wr, S, B, window_offset=0 if by_boot else wl.get("w0", rank * Wr),
@@ -766,7 +769,9 @@ def main():
                                          for n in ("c2", "c4", "g351", "ref1000_c3", "ref1000_g351") if n != args.workload}
             if not args.no_c5_full and args.workload != "c5":
                 result["extra_workloads"]["c5_full_shard"] = c5_full_shard(A, ctx, seed)
-            if not args.strict_order:   # what the reference's summation order costs on this workload
+            # what the reference's summation order costs on this workload (not on the streamed C5 shapes: N = 20 100 serial
+            # additions per evaluation take minutes, and with --workload c5 a second 76 GB plan beside the open one)
+            if not args.strict_order and args.workload not in ("c5", "c5s"):
                 so = quick_workload(A, ctx, args.workload, seed, strict_order=1)
                 so["price"] = fits_per_s / so["fits_per_s"]
                 so["what"] = ("abn_options.strict_order = 1 (serial row-order residual sums, bit-equal to the oracle's "

@@ -60,7 +60,11 @@ typedef struct abn_options {
                                            four) wavefronts per chain and reproduce the same tree bit for bit     */
   int32_t strict_order;                 /* 1 = every cost sums its residuals serially in row order, the reference's
                                            `square_sum += ...` (src/structs.rs:206-213): cost AND fit entry points,
-                                           bit-equal to the oracle's lanes = 1; abn_fit_info.lanes reports 1     */
+                                           bit-equal to the oracle's lanes = 1; abn_fit_info.lanes reports 1.
+                                           0 = auto: serial for pedigrees of up to 16 rows (free there; the bundled
+                                           data/ pedigree is then in the reference's order by default), else the
+                                           pedigree's reduction tree.  -1 = the tree whatever the size.  Like the
+                                           tree a function of the pedigree and the options, never of the launch    */
   int32_t shrink_on_failed_contraction; /* 0 = argmin 0.8.1 behaviour; 1 = textbook Nelder-Mead        */
   int32_t max_iters_start;              /* 10000, src/ab_neutral.rs:62                                 */
   int32_t max_iters_boot;               /* 1000,  src/boot_model.rs:81                                 */

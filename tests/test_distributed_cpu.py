@@ -87,7 +87,7 @@ def test_gloo_shard_and_gather_matches_unsharded(world, W, B, mode):
     assert ok and got_mode == mode and shape == (W, B, 7)
 
 
-def _failing_worker(rank, world, port, q):
+def _failing_worker(rank, world, port, q, kind="nan_window"):
     sys.path.insert(0, str(ROOT))
     import torch.distributed as dist
 
@@ -105,6 +105,20 @@ def _failing_worker(rank, world, port, q):
                 out[i] = np.nan
         return out
 
+    if kind == "shard_error":  # the last rank's runner failed (what hip_shard_runner records when abn_plan_sync reports a
+        def compute_err(shard):  # lost chain): finite rows, an `error` attribute — nothing the NaN scan could see
+            if rank == world - 1:
+                compute_err.error = A.AbnError(4, "persistent fit launch of phase B finished 23 999 of 24 000 chains")
+            return np.ones((shard.n_windows, shard.n_boot, 7))
+
+        compute_err.error = None
+        compute = compute_err
+    elif kind == "count_only":  # the runner reports a failed window the table does not show (a reporting runner is believed)
+        def compute_cnt(shard):
+            compute_cnt.failed_windows = 1 if rank == 0 else 0
+            return np.ones((shard.n_windows, shard.n_boot, 7))
+
+        compute = compute_cnt
     try:
         D_.run_sharded(compute, 3, 4)
         q.put((rank, "no error"))
@@ -132,6 +146,25 @@ def test_a_failed_window_raises_on_every_rank():
     assert got == [(0, "AbnError 5"), (1, "AbnError 5")]
 
 
+@pytest.mark.parametrize("kind,status", [("shard_error", 4), ("count_only", 5)])
+def test_a_failed_shard_raises_on_every_rank(kind, status):
+    """failures are exchanged explicitly (an all-reduce next to the gather), not inferred from NaN rows: a rank
+    whose plan reported ABN_ERR_HIP at abn_plan_sync, or a failed-window count, makes EVERY rank raise."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q, kind)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == [(0, f"AbnError {status}"), (1, f"AbnError {status}")]
+
+
 def test_reduction_tree_is_a_function_of_the_pedigree_only(abn):
     """abn_reduction_tree takes generations and options — no fit counts: the tree cannot change with sharding.
     Auto: the canonical 64-accumulator tree (0x10040) for every LDS-resident pedigree, whatever lane count its packed
@@ -141,7 +174,10 @@ def test_reduction_tree_is_a_function_of_the_pedigree_only(abn):
 
     canon = 0x10040
     assert abn.reduction_tree(synthetic.c3_pedigree()[0][:, :3]) == canon
-    assert abn.reduction_tree(O.load_pedigree(ROOT / "tests" / "golden" / "pedigree_generated.txt")[:, :3]) == canon
+    bundled = O.load_pedigree(ROOT / "tests" / "golden" / "pedigree_generated.txt")[:, :3]
+    assert abn.reduction_tree(bundled) == 1          # up to 16 rows: the reference's serial order by default (free there)
+    assert abn.reduction_tree(bundled, abn.default_options(strict_order=-1)) == canon
+    assert abn.reduction_tree(synthetic.c3_pedigree()[0][:17, :3]) == canon    # 17 rows: the tree
     assert abn.reduction_tree(O.load_pedigree(ROOT / "tests" / "golden" / "pedigree.txt")[:, :3]) == canon
     assert abn.reduction_tree(synthetic.c3_pedigree()[0][:, :3], abn.default_options(lanes_per_chain=32)) == 32
     assert abn.reduction_tree(synthetic.c3_pedigree()[0][:, :3], abn.default_options(lanes_per_chain=16)) == 16

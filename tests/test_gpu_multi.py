@@ -21,7 +21,7 @@ def _pedigree(kind, golden):
     if kind == "c3":                      # N = 105: packed kernels with 16 lanes per chain (four accumulators each)
         ped, p0 = synthetic.c3_pedigree()
         return ped, p0
-    if kind == "generated":               # N = 6: packed kernels with 8 lanes per chain
+    if kind.startswith("generated"):      # N = 6: packed kernels with 8 lanes per chain
         return golden["generated"], golden["p0uu_generated"]
     if kind == "mid":                     # N = 200: packed kernels with 32 lanes per chain
         rng = np.random.default_rng(5)
@@ -36,7 +36,8 @@ def _pedigree(kind, golden):
 CANON = 0x10040   # the canonical tree of every LDS-resident pedigree: 64 accumulators, high lane bits first
 
 
-@pytest.mark.parametrize("kind,tree", (("c3", CANON), ("generated", CANON), ("mid", CANON), ("golden351", CANON)))
+@pytest.mark.parametrize("kind,tree", (("c3", CANON), ("generated", 1), ("generated_tree", CANON), ("mid", CANON),
+                                       ("golden351", CANON)))
 def test_results_do_not_depend_on_launch_size(abn, gpu_ctx, golden, oracle, kind, tree):
     """Auto options.  The same window fitted (1) alone — both phases on the four-wavefront speculative kernel —,
     (2) among 50 windows — phase B (2000 bootstraps) one wavefront per chain —, (3) among 200 windows — phase A one
@@ -44,11 +45,14 @@ def test_results_do_not_depend_on_launch_size(abn, gpu_ctx, golden, oracle, kind
     byte-identical models, residuals, bootstrap rows, iteration and evaluation counts: the reduction tree is the
     pedigree's, whichever kernel a launch picks.  Window 0 is also checked against the oracle."""
     ped, p0 = _pedigree(kind, golden)
-    assert abn.reduction_tree(ped[:, :3]) == tree
+    # the bundled six-row pedigree: serial row-order sums by default (tree code 1: pedigrees of up to 16 rows are summed in
+    # the reference's order), the canonical tree with strict_order = -1 — both independent of the launch
+    order = -1 if kind == "generated_tree" else 0
+    assert abn.reduction_tree(ped[:, :3], abn.default_options(strict_order=order)) == tree
     n = ped.shape[0]
     S, B, seed = 8, 40, 31
     iters_a, iters_b = (300, 150) if n > 200 else (2000, 1000)
-    o = abn.default_options(seed=seed, max_iters_start=iters_a, max_iters_boot=iters_b)
+    o = abn.default_options(seed=seed, max_iters_start=iters_a, max_iters_boot=iters_b, strict_order=order)
     outs = []
     for W in (1, 50, 200, 800):
         rng = np.random.default_rng(17)

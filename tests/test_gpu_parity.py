@@ -348,10 +348,10 @@ def test_alphabeta_cli_end_to_end(abn, gpu_ctx, golden, oracle, tmp_path):
     raw = np.load(tmp_path / "raw.npy")
     assert raw.shape == (iters, 7)
     ped, p0 = golden["generated"], golden["p0uu_generated"]
-    # auto options: the canonical 64-accumulator tree whichever kernel runs (here four wavefronts per chain in
-    # both phases)
+    # auto options on the bundled six-row pedigree: the REFERENCE's serial row-order sums (pedigrees of up to 16 rows;
+    # tree code 1), whichever kernel runs (here four wavefronts per chain in both phases)
     tree = abn.reduction_tree(ped[:, :3])
-    assert tree == 0x10040
+    assert tree == 1
     k, model, pred, resid, _, _ = _oracle_ab_neutral(oracle, abn, ped, p0, p0, 1.0, iters, seed, tree)
     wraw, _ = oracle.boot_model(ped, model, pred, resid, p0, p0, 1.0, seed, 0, 0, iters, lanes=tree)
     assert np.array_equal(raw, wraw)
@@ -753,8 +753,9 @@ def test_fixed_point_skip_changes_no_output(abn, gpu_ctx, golden, oracle):
         _assert_fits_equal(res[0][0], res[0][1], want)
 
 
+@pytest.mark.parametrize("order", (-1, 0))   # the canonical tree / the serial default of a six-row pedigree (STRICT variant)
 @pytest.mark.parametrize("variant,no_skip,iters", ((1, 0, 10000), (0, 1, 400), (0, 0, 10000), (0, 0, 0), (0, 1, 1), (1, 0, 2)))
-def test_speculative_phase_a_all_branches(abn, gpu_ctx, golden, oracle, variant, no_skip, iters):
+def test_speculative_phase_a_all_branches(abn, gpu_ctx, golden, oracle, variant, no_skip, iters, order):
     """Phase A of a small plan runs on abn_fit_spec_kernel (three evaluation wavefronts + the keeper).  Its
     rare branches — NelderMead::shrink after a NaN reflection cost or, in the textbook variant, after a
     rejected contraction; the repeated iterations of a stuck fit — must follow the oracle bit for bit."""
@@ -765,7 +766,7 @@ def test_speculative_phase_a_all_branches(abn, gpu_ctx, golden, oracle, variant,
     D[3, 2] = np.nan                      # every cost of window 3 is NaN: a shrink per iteration
     p0w = rng.uniform(0.6, 0.8, W)
     o = abn.default_options(seed=seed, shrink_on_failed_contraction=variant, no_fixed_point_skip=no_skip,
-                            max_iters_start=iters)
+                            max_iters_start=iters, strict_order=order)
     plan = abn.Plan(gpu_ctx, ped[:, :3], W, S, 0, options=o)
     plan.set_windows(D, p0w)
     plan.run_phase(0)
@@ -775,7 +776,7 @@ def test_speculative_phase_a_all_branches(abn, gpu_ctx, golden, oracle, variant,
     out = plan.download(allow_failed_windows=True)
     plan.close()
     la = int(out["info_a"]["lanes"][0, 0])
-    assert la == 0x10040 == abn.reduction_tree(ped[:, :3])   # the canonical tree, on four wavefronts per chain
+    assert la == (0x10040 if order < 0 else 1) == abn.reduction_tree(ped[:, :3], o)   # on four wavefronts per chain
     assert out["best_start"][3] == -1 and np.all(out["info_a"]["status"][3] == 2)
     assert np.all(np.isnan(out["models"][3])) and np.all(np.isnan(out["pred"][3]))
     for w in range(W):
@@ -807,14 +808,15 @@ def test_persistent_refill_kernel_is_schedule_independent(abn, gpu_ctx, golden, 
     D = np.abs(ped[:, 3][None, :] * rng.uniform(0.8, 1.25, (W, 1)))
     p0w = np.clip(p0 * rng.uniform(0.9, 1.1, W), 0.05, 0.95)
     outs = []
-    for groups in (1, 2):
-        plan = abn.Plan(gpu_ctx, ped[:, :3], W, S, B, options=abn.default_options(seed=seed, window_groups=groups))
+    for groups in (1, 2):     # strict_order = -1: the tree kernels (the serial default of a six-row pedigree has no persistent form)
+        plan = abn.Plan(gpu_ctx, ped[:, :3], W, S, B,
+                        options=abn.default_options(seed=seed, window_groups=groups, strict_order=-1))
         plan.set_windows(D, p0w)
         plan.run()
         outs.append(plan.download())
         plan.close()
     lanes = int(outs[0]["info_b"]["lanes"][0, 0])          # the canonical tree code, whatever the packed lane count
-    assert lanes == abn.reduction_tree(ped[:, :3]) == 0x10040
+    assert lanes == abn.reduction_tree(ped[:, :3], abn.default_options(strict_order=-1)) == 0x10040
     packed = 8 if case == "generated" else 16
     assert W * B // (64 // packed) > 3072                 # the persistent launch was taken
     for k in ("models", "pred", "resid", "raw", "best_start"):
@@ -829,6 +831,63 @@ def test_persistent_refill_kernel_is_schedule_independent(abn, gpu_ctx, golden, 
         assert np.array_equal(out["raw"][w], raw, equal_nan=True)
         for k in ("iters", "evals", "status"):
             assert np.array_equal(out["info_b"][w][k], res[k]), k
+
+
+def test_lost_fifo_entry_is_an_error_at_sync(abn):
+    """a parked chain whose FIFO entry never appears must not end as uninitialised rows under ABN_OK on
+    the paths that never call abn_plan_download — the torch.distributed shard runner reads a bound buffer after
+    abn_plan_sync.  Fault injection on the -DABN_MEASUREMENT_KNOBS build (build/libabn_knobs.so, made by build()): the first
+    entry of FIFO shard 0 is never published; the launch must still end (bounded spin) and abn_plan_sync,
+    abn_plan_failed_windows and abn_plan_download must each report ABN_ERR_HIP.  A subprocess: the variant library is a
+    second copy of the product library."""
+    import subprocess
+    import sys
+    import textwrap
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    lib = root / "build" / "libabn_knobs.so"
+    if not lib.exists():
+        from alphabeta_rs_amd import build as B
+
+        B.build_knobs()
+    code = textwrap.dedent("""
+        import numpy as np
+        import alphabeta_rs_amd as A
+        from alphabeta_rs_amd import synthetic
+        ped, p0 = synthetic.c3_pedigree()
+        W, S, B = 8, 4, 3000                 # 24 000 bootstrap chains of 16 lanes: the time-sliced persistent launch
+        rng = np.random.default_rng(3)
+        D = np.abs(ped[:, 3][None, :] * rng.uniform(0.9, 1.1, (W, 1)))
+        with A.Context(0) as ctx:
+            plan = A.Plan(ctx, ped[:, :3], W, S, B, options=A.default_options(seed=11))
+            plan.set_windows(D, np.full(W, p0))
+            plan.run()
+            seen = []
+            for what in (plan.sync, plan.failed_windows, plan.download):
+                try:
+                    what()
+                    seen.append("ok")
+                except A.AbnError as e:
+                    seen.append(e.status_name if hasattr(e, "status_name") else str(e))
+            print("KERNELS", plan.last_kernels())
+            print("SEEN", seen)
+            plan.close()
+    """)
+    import os
+
+    def run(drop):
+        env = dict(os.environ, ABNEUTRAL_HIP_LIB=str(lib), ABN_DROP_FIFO_ENTRY=drop, PYTHONPATH=str(root))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout
+
+    out = run("0")                               # the same build without the fault: all three succeed
+    assert out.count("ok") == 3, out
+    out = run("1")
+    seen = out.split("SEEN", 1)[1]
+    assert seen.count("ABN_ERR_HIP") == 3 and "ok" not in seen, out
+    assert "finished" in seen and "chains" in seen, out     # the message names the count
 
 
 def test_reference_unit_tests_through_the_cpp_mirror(abn, gpu_ctx):

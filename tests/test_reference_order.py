@@ -71,8 +71,10 @@ def compare(ref, got, raw_same_model, name, max_starts, max_rows, max_frac):
 @pytest.mark.parametrize("name", ["generated", "sparse", "pedigree", "c3"])
 def test_tree_order_fit_is_within_1e6_of_reference_order(oracle, abn, golden, name):
     ped, p0, S, B, max_starts, max_rows, max_frac = _cases(golden)[name]
-    tree = abn.reduction_tree(ped[:, :3])           # the product's order for this pedigree (host arithmetic)
+    tree = abn.reduction_tree(ped[:, :3], abn.default_options(strict_order=-1))   # the pedigree's tree (host arithmetic)
     assert tree == 0x10040
+    # the DEFAULT order: the tree, except for pedigrees of up to 16 rows — the bundled one — which are summed serially
+    assert abn.reduction_tree(ped[:, :3]) == (1 if ped.shape[0] <= 16 else tree)
     ref = oracle_pipeline(oracle, ped, p0, S, B, 1)
     got = oracle_pipeline(oracle, ped, p0, S, B, tree)
     same, _ = oracle.boot_model(ped, ref["model"], ref["pred"], ref["resid"], p0, p0, 1.0, SEED, 0, 0, B, lanes=tree)
@@ -102,7 +104,22 @@ def test_hip_auto_options_against_reference_order(oracle, abn, gpu_ctx, golden, 
     opts = abn.default_options(seed=SEED)
     got = hip_pipeline(abn, gpu_ctx, ped, p0, S, B, opts)
     same, _ = gpu_ctx.boot_model_run(ped, ref["model"], ref["pred"], ref["resid"], p0, p0, 1.0, B, options=opts)
+    if name == "generated":
+        # the bundled data/ pedigree (C1 / C2, the north star's parity target) is in the reference's
+        # order BY DEFAULT — 0 starts and 0 rows apart, every bit
+        assert np.all(got["info_a"]["lanes"] == 1) and np.all(got["res"]["lanes"] == 1)
+        for k in ("model", "pred", "resid", "raw"):
+            assert np.array_equal(got[k], ref[k]), k
+        assert np.array_equal(got["info_a"]["evals"], ref["fits"]["evals"]) and np.array_equal(same, ref["raw"])
+        max_starts = max_rows = max_frac = 0
     compare(ref, got, same, name, max_starts, max_rows, max_frac)
+    if name == "generated":   # the tree on the same pedigree (strict_order = -1) stays inside the bounds of round 3
+        max_starts, max_rows, max_frac = _cases(golden)[name][4:]
+        topts = abn.default_options(seed=SEED, strict_order=-1)
+        tgot = hip_pipeline(abn, gpu_ctx, ped, p0, S, B, topts)
+        tsame, _ = gpu_ctx.boot_model_run(ped, ref["model"], ref["pred"], ref["resid"], p0, p0, 1.0, B, options=topts)
+        assert np.all(tgot["res"]["lanes"] == 0x10040)
+        compare(ref, tgot, tsame, name + " (tree)", max_starts, max_rows, max_frac)
 
 
 @pytest.mark.gpu
