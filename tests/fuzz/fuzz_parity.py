@@ -15,14 +15,14 @@ def rand_ped(rng, n, tmax):
     d = np.abs(rng.normal(0.01, 0.004, n))
     return np.stack([t0, t1, t2, d], axis=1).astype(np.float64)
 
-def main(seconds=120, seed=0):
+def main(seconds=120, seed=0, max_cases=None):
     ctx = A.Context(0)
     rng = np.random.default_rng(seed)
     t_end = time.time() + seconds
     cases = fails = 0
     t_note = time.time()
-    while time.time() < t_end:
-        n = int(rng.choice([1, 2, 5, 17, 64, 65, 105, 129, 300, 513, 700]))
+    while time.time() < t_end and (max_cases is None or cases < max_cases):
+        n = int(rng.choice([1, 2, 5, 16, 17, 64, 65, 105, 129, 300, 513, 700]))
         tmax = int(rng.choice([0, 1, 3, 8, 20, 40]))
         ped = rand_ped(rng, n, tmax)
         p0 = float(rng.uniform(0.5, 0.99))
@@ -35,7 +35,8 @@ def main(seconds=120, seed=0):
             s0 *= rng.uniform(-3, 50, s0.shape)           # wild starts: negative rates, huge weights
         if rng.random() < 0.1:
             s0[0, int(rng.integers(0, 5)), int(rng.integers(0, 4))] = np.nan
-        strict = int(rng.random() < 0.15)                 # serial row-order sums: info.lanes == 1, oracle lanes = 1
+        # serial row-order sums (1; and 0 = auto for pedigrees of up to 16 rows): info.lanes == 1, oracle lanes = 1; -1: the tree
+        strict = int(rng.choice([-1, 0, 1], p=[0.25, 0.6, 0.15]))
         o = A.default_options(lanes_per_chain=lanes, shrink_on_failed_contraction=variant, strict_order=strict)
         eqp, ew = float(rng.uniform(0.3, 0.9)), float(rng.choice([0.0, 0.7, 1.0]))
         try:

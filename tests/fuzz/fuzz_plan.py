@@ -9,13 +9,13 @@ import alphabeta_rs_amd as A
 import oracle as O
 from fuzz_parity import rand_ped
 
-def main(seconds=180, seed=0):
+def main(seconds=180, seed=0, max_cases=None):
     ctx = A.Context(0)
     rng = np.random.default_rng(seed)
     t_end = time.time() + seconds
     cases = fails = 0
     t_note = time.time()
-    while time.time() < t_end:
+    while time.time() < t_end and (max_cases is None or cases < max_cases):
         n = int(rng.choice([3, 6, 40, 105, 200, 600]))
         tmax = int(rng.choice([1, 4, 8, 16]))
         ped = rand_ped(rng, n, tmax)
@@ -29,7 +29,8 @@ def main(seconds=180, seed=0):
         mid = (not big) and n in (40, 105) and rng.random() < 0.12   # one window that just about fills the GPU: 2048 persistent wavefronts
         if mid:
             W, S, B = 1, int(rng.choice([3, 10])), int(rng.choice([8300, 10000, 12000]))
-        strict = int(rng.random() < 0.15)             # serial row-order sums (oracle lanes = 1)
+        # 1: serial row-order sums (oracle lanes = 1); 0: auto (serial up to 16 rows: n = 3, 6); -1: the tree whatever the size
+        strict = int(rng.choice([-1, 0, 1], p=[0.3, 0.55, 0.15]))
         skip_off = int(rng.random() < 0.2)
         mi_a, mi_b = int(rng.choice([1500, 3000])), int(rng.choice([100, 400]))
         variant = int(rng.integers(0, 2))
