@@ -86,6 +86,12 @@ def make_workload(name: str, rank: int, world: int):
                     label="C5 shard: synthetic deep pedigree, 8 lineages x 125 generations (N=20100 rows, T=125, "
                           "K=950), 4 starts + 4096 bootstraps, 1 window per GPU; rows streamed (the materialised "
                           "bootstrap observations, 8 B/row, re-read from HBM every evaluation)")
+    if name == "c5p":
+        # the stream probe of every bench line (stream_probe) as a workload of its own, so that scripts/profile_round.sh can
+        # take its counters: the C5 pedigree, 2 starts + 8192 bootstraps, one window
+        ped, p = synthetic.c5_pedigree()
+        return dict(gens=ped[:, :3], D=ped[:, 3][None, :], p0=np.array([p]), S=2, B=8192, wr=1,
+                    label="C5 stream probe: deep pedigree (N=20100 rows, T=125, K=950), 2 starts + 8192 bootstraps, rows streamed")
     if name in ("c2", "g351"):
         # fixtures are data (tests/golden); read without the oracle package
         fn = "pedigree_generated.txt" if name == "c2" else "pedigree.txt"
@@ -184,22 +190,52 @@ def kernel_source_sha1() -> str:
 
 
 def measured_traffic(workload: str):
-    """HBM bytes per phase-B launch from the committed rocprofv3 PMC passes (profiles/rNN_pmc_fit_boot_<wl>.json,
-    written by scripts/profile_round.sh) — used only when that profile was taken on the kernel sources of this very
-    build; a stale profile yields null and says so."""
+    """The committed rocprofv3 PMC passes of a workload (profiles/rNN_pmc_<workload>.json, written per phase by
+    scripts/profile_round.sh + profiles/summarize_rocprof.py) — used only when that profile was taken on the kernel
+    sources of this very build; a stale profile yields None and says so.  Returns (phases | None, source note)."""
     sha = kernel_source_sha1()
-    cands = sorted((ROOT / "profiles").glob(f"r*_pmc_fit_boot_{workload}.json"), reverse=True)
-    for f in cands:
+    for f in sorted((ROOT / "profiles").glob(f"r*_pmc_{workload}.json"), reverse=True):
         try:
             j = json.loads(f.read_text())
         except Exception:
             continue
-        if j.get("workload") == workload and j.get("source_sha1") == sha:
-            return j.get("hbm_bytes_per_launch"), {"file": f"profiles/{f.name}", "source_sha1": sha,
-                                                   "kernel": j.get("kernel"), "collected": j.get("collected"),
-                                                   "sq_insts_valu_per_launch": j.get("sq_insts_valu_per_launch")}
+        if j.get("workload") == workload and j.get("source_sha1") == sha and "phases" in j:
+            return j["phases"], {"file": f"profiles/{f.name}", "source_sha1": sha, "collected": j.get("collected")}
     return None, {"note": "no rocprofv3 PMC profile of this build's kernel sources under profiles/ "
                           f"(source_sha1 {sha[:12]}); run scripts/profile_round.sh", "source_sha1": sha}
+
+
+def valu_issue(ph, kern_s):
+    """How busy the vector pipe was over a launch, from the SQ counters of the stamped profile of that launch:
+    SQ_INSTS_VALU wavefront instructions, SQ_ACTIVE_INST_VALU quad-cycles a wavefront had a vector instruction in
+    execution.  cycles_per_inst = 4 ACTIVE / INSTS is the MEASURED issue cost of this kernel's instruction mix (f64
+    arithmetic 4 cycles, 32-bit moves / selects / DPP fewer, divisions and square roots more) — the peak instruction rate
+    follows from it instead of from a flat 4 cycles; busy_frac = the share of SIMD-cycles of the launch spent issuing."""
+    if not ph or "SQ_INSTS_VALU" not in ph or kern_s <= 0:
+        return None
+    nv = ph["SQ_INSTS_VALU"]
+    out = {"insts_per_launch": nv, "achieved_ginst_per_s": nv / kern_s / 1e9, "kernel": ph.get("kernel")}
+    act = ph.get("SQ_ACTIVE_INST_VALU")
+    if act:
+        cpi = 4.0 * act / nv
+        peak = N_SIMDS * CLOCK_HZ / cpi
+        out.update({"issue_cycles_per_inst": cpi, "peak_ginst_per_s": peak / 1e9, "frac": nv / kern_s / peak,
+                    "what": "wavefront vector instructions / s against 1024 SIMDs x 2.4 GHz / (measured issue cycles per "
+                            "instruction = 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU); frac = share of the launch's "
+                            "SIMD-cycles spent issuing vector instructions (tail of long chains included)"})
+    else:
+        peak = N_SIMDS * CLOCK_HZ / 4.0
+        out.update({"peak_ginst_per_s": peak / 1e9, "frac": nv / kern_s / peak,
+                    "what": "wavefront vector instructions / s against 1024 SIMDs x 2.4 GHz / 4 (no SQ_ACTIVE_INST_VALU pass)"})
+    for k_in, k_out in (("SQ_INSTS_SALU", "scalar_insts_per_launch"), ("SQ_INSTS_LDS", "lds_insts_per_launch"),
+                        ("SQ_WAVES", "wavefronts")):
+        if k_in in ph:
+            out[k_out] = ph[k_in]
+    if "SQ_WAVE_CYCLES" in ph and ph["SQ_WAVE_CYCLES"] > 0:   # where the resident wavefront-cycles went
+        wc = ph["SQ_WAVE_CYCLES"]
+        out["of_wavefront_cycles"] = {k: ph[c] / wc for k, c in (("issuing", "SQ_ACTIVE_INST_ANY"), ("waiting_to_issue", "SQ_WAIT_INST_ANY"),
+                                                                 ("waiting_on_counter", "SQ_WAIT_ANY")) if c in ph}
+    return out
 
 
 def pcie_inclusive(A, ctx, wl, opts, reps=5):
@@ -242,6 +278,10 @@ def quick_workload(A, ctx, name, seed, steps=3, **options):
     r = {"workload": wl["label"], "fits_per_s": cnt["fits"] / dt, "ms_per_step": 1e3 * dt, "steps": steps,
          "candidate_evals_per_s": (cnt["evals"] - cnt["evals_skipped"]) / dt, "kernel_ms": kms,
          "kernels": {k: f"{v[0]} ({v[1]} lanes per chain)" for k, v in kern.items()}}
+    phases, src = measured_traffic(name)
+    if phases:   # counters of the stamped rocprofv3 profile of this workload (scripts/profile_round.sh)
+        r["pmc"] = {"source": src, **{p: {"traffic": ph.get("hbm_bytes_per_launch"), "valu_issue": valu_issue(ph, kms[p] * 1e-3)}
+                                       for p, ph in phases.items() if p in kms}}
     if out["info_a"] is not None:   # starts that reached argmin's fixed point (ABN_FIT_MAX_ITERS after a rejected contraction)
         r["starts_at_max_iters"] = int((out["info_a"]["status"] == 1).sum())
         r["boots_at_max_iters"] = int((out["info_b"]["status"] == 1).sum())
@@ -258,6 +298,7 @@ def pairwise_bench(A, ctx, shapes=((15, 4_000_000), (15, 32_000_000), (50, 32_00
     import torch
 
     out = []
+    pw_prof, pw_src = measured_traffic("pw")     # {"<n>x<L>": bytes} written by scripts/pw_profile.sh
     for n, L in shapes:
         g = torch.Generator(device="cuda")
         g.manual_seed(1234 + n)
@@ -277,11 +318,12 @@ def pairwise_bench(A, ctx, shapes=((15, 4_000_000), (15, 32_000_000), (50, 32_00
         gbs = n * L / (avg * 1e-3) / 1e9
         out.append({"samples": n, "sites": L, "pairs": npairs, "kernel_ms_avg": avg, "kernel_ms_min": best,
                     "code_bytes": n * L, "achieved_GBps": gbs, "peak_GBps": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS,
+                    "traffic": (pw_prof or {}).get(f"{n}x{L}"),   # HBM bytes of the scan launch (FETCH_SIZE x 2, stamped profile)
                     "site_pairs_per_s": npairs * L / (avg * 1e-3), "sane": ok})
         del codes
     return {"kernel": "abn_pairwise_mx_kernel (v_mfma_i32_16x16x64_i8 Gram products) + abn_pairwise_reduce_tiles_kernel", "bound": "hbm", "unit": "GB/s",
             "what": "n*L code bytes (one pass) / HIP-event time of the call's kernels, inputs resident in HBM",
-            "shapes": out}
+            "traffic_source": pw_src, "shapes": out}
 
 
 def stream_probe(A, ctx, seed, steps=2, every=5, B=8192, tag="C5 shard"):
@@ -318,8 +360,12 @@ def stream_probe(A, ctx, seed, steps=2, every=5, B=8192, tag="C5 shard"):
     alg = evals_b * (4 * N + 40) + B * 112 + N * 18
     streamed = evals_b * (8 * N + 40) + B * (12 * N + 112)
     achieved = alg / (ms * 1e-3) / 1e9
+    # counters of the same launch (workload `c5p` = this probe) from the stamped profile, if there is one for this build
+    phases, src = measured_traffic("c5p") if (every == 5 and B == 8192) else (None, {"note": "no profile of this variant"})
+    ph_b = (phases or {}).get("fit_boot")
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None, "kernel": f"abn_fit_kernel<G={lanes & 0xff}, stream> phase B (+ abn_make_dstar_kernel)",
+            "traffic": ph_b.get("hbm_bytes_per_launch") if ph_b else None, "traffic_source": src,
+            "kernel": f"abn_fit_kernel<G={lanes & 0xff}, stream> phase B (+ abn_make_dstar_kernel)",
             "kernel_ms": ms, "algorithmic_bytes_per_launch": alg, "streamed_bytes_per_launch": streamed,
             "beyond_l2_GBps": streamed / (ms * 1e-3) / 1e9,
             "beyond_l2_frac_of_hbm_peak": streamed / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -358,12 +404,15 @@ def c5_full_shard(A, ctx, seed, steps=1):
     alg = evals_b * (4 * N + 40) + fits_b * 112 + W * N * 16 + N * 2
     streamed = evals_b * (8 * N + 40) + fits_b * (12 * N + 112)
     sane = bool(np.isfinite(out["raw"]).all() and (out["best_start"] >= 0).all())
-    return {"workload": wl["label"], "fits_per_s": cnt["fits"] / dt, "ms_per_step": 1e3 * dt, "steps": steps,
+    phases, src = measured_traffic("c5")
+    ph_b = (phases or {}).get("fit_boot")
+    return {"workload": wl["label"], "traffic_source": src, "fits_per_s": cnt["fits"] / dt, "ms_per_step": 1e3 * dt, "steps": steps,
             "candidate_evals_per_s": (cnt["evals"] - cnt["evals_skipped"]) / dt, "kernel_ms": kms,
             "kernels": {k: f"{v[0]} ({v[1]} lanes per chain)" for k, v in kern.items()},
             "plan_device_bytes": dev_bytes, "all_rows_finite": sane,
             "roofline": {"bound": "hbm", "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": ms,
+                         "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "traffic": ph_b.get("hbm_bytes_per_launch") if ph_b else None, "kernel_ms": ms,
                          "kernel": "abn_fit_kernel<64, stream> phase B (+ abn_make_dstar_kernel)",
                          "algorithmic_bytes_per_launch": alg, "streamed_bytes_per_launch": streamed,
                          "beyond_l2_GBps": streamed / (ms * 1e-3) / 1e9,
@@ -494,7 +543,9 @@ def single_process_main(args) -> None:
         "candidate_evals_per_s": evals / dt, "fits_per_step": fits, "evals_per_step": evals,
         "kernel_ms_per_device": kms, "all_rows_finite": sane,
         "roofline": {"bound": "hbm", "achieved": alg0 / kern_s / 1e9 if kern_s > 0 else 0.0, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": (alg0 / kern_s / 1e9 if kern_s > 0 else 0.0) / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": (alg0 / kern_s / 1e9 if kern_s > 0 else 0.0) / HBM_PEAK_GBS,
+                     "traffic": ((measured_traffic(args.workload)[0] or {}).get("fit_boot") or {}).get("hbm_bytes_per_launch")
+                     if n == 1 else None,
                      "kernel": "phase-B fit kernel of device 0's shard (slowest device's HIP-event time)",
                      "kernel_ms": kern_s * 1e3, "algorithmic_bytes_per_launch": alg0,
                      "note": "LDS-resident fits: nominal HBM roofline, see the process-per-GPU line for valu_issue"},
@@ -512,7 +563,7 @@ def main():
                     help="timed steps (default 200 for the millisecond workloads — long enough for a 5 s GPU-busy "
                          "sampler to see the run —, 20 for g351 / mp, 5 for c5s, 1 for the 6 s steps of c5)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c4s", "g351", "c5s", "c5", "mp", "pw",
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c4", "c4s", "g351", "c5s", "c5p", "c5", "mp", "pw",
                                                          "ref1000_c3", "ref1000_g351"])
     ap.add_argument("--single-process", action="store_true",
                     help="time abn_multi_* — ONE process driving the devices of --devices, RCCL gather inside the library "
@@ -545,7 +596,7 @@ def main():
                          "256 MiB Infinity Cache (slow to set up: a 123k-row pedigree)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"c5": 1, "c5s": 5, "g351": 20, "mp": 20, "pw": 20, "ref1000_c3": 20, "ref1000_g351": 20}.get(args.workload, 200)
+        args.steps = {"c5": 1, "c5s": 5, "c5p": 5, "g351": 20, "mp": 20, "pw": 20, "ref1000_c3": 20, "ref1000_g351": 20}.get(args.workload, 200)
     if args.warmup is None:
         args.warmup = 1 if args.workload == "c5" else 3
     if args.single_process:
@@ -602,7 +653,7 @@ def main():
                           "config": {"workload": f"pairwise divergence, {big['samples']} samples x {big['sites']} sites, "
                                                  "codes resident in HBM"},
                           "roofline": {"bound": "hbm", "achieved": big["achieved_GBps"], "peak": HBM_PEAK_GBS,
-                                       "unit": "GB/s", "frac": big["frac"], "traffic": None},
+                                       "unit": "GB/s", "frac": big["frac"], "traffic": big.get("traffic")},
                           "pairwise": r}), flush=True)
         os.dup2(2, 1)
         ctx.close()
@@ -712,7 +763,11 @@ def main():
         achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
         flops_eval = 45 * T + 53 * K + 4 * N + 60
         valu_tflops = evals_b * flops_eval / kern_s / 1e12 if kern_s > 0 else 0.0
-        traffic, traffic_source = measured_traffic(args.workload)
+        phases, traffic_source = measured_traffic(args.workload)
+        ph_b = (phases or {}).get("fit_boot")
+        traffic = ph_b.get("hbm_bytes_per_launch") if ph_b else None
+        if ph_b:
+            traffic_source = dict(traffic_source, kernel=ph_b.get("kernel"))
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -731,15 +786,14 @@ def main():
             "valu_fp64": {"achieved_tflops": valu_tflops, "peak_tflops": FP64_VALU_PEAK_TFLOPS,
                           "frac": valu_tflops / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": flops_eval},
         }
-        # how busy the vector pipe is: wavefront vector instructions of the launch (SQ_INSTS_VALU of the stamped PMC
-        # profile) x 4 issue cycles against SIMDs x clock x launch time.  The roof the resident kernel actually runs
-        # under: with three wavefronts on a SIMD it is ~90 % busy; the launch average includes the tail of long chains.
-        nv = traffic_source.pop("sq_insts_valu_per_launch", None)
-        if nv and not stream:
-            peak = N_SIMDS * CLOCK_HZ / 4.0
-            roofline["valu_issue"] = {"insts_per_launch": nv, "achieved_ginst_per_s": nv / kern_s / 1e9,
-                                      "peak_ginst_per_s": peak / 1e9, "frac": nv / kern_s / peak,
-                                      "what": "wavefront vector instructions / s against 1024 SIMDs x 2.4 GHz / 4"}
+        # how busy the vector pipe is (the roof the resident kernels actually run under), per phase, from the stamped profile
+        vi = valu_issue(ph_b, kern_s)
+        if vi:
+            roofline["valu_issue"] = vi
+        vi_a = valu_issue((phases or {}).get("fit_starts"), kms["fit_starts"] * 1e-3)
+        if vi_a:
+            roofline["phase_a"] = {"kernel_ms": kms["fit_starts"], "valu_issue": vi_a,
+                                   "traffic": (phases or {}).get("fit_starts", {}).get("hbm_bytes_per_launch")}
         result = {
             "metric": "ABneutral model fits/sec (pedigree x bootstraps x windows)",
             "value": fits_per_s, "unit": "fits/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -766,7 +820,8 @@ def main():
             if Wr == 1:
                 result["pcie_inclusive"] = pcie_inclusive(A, ctx, wl, opts)
             result["extra_workloads"] = {n: quick_workload(A, ctx, n, seed)
-                                         for n in ("c2", "c4", "g351", "ref1000_c3", "ref1000_g351") if n != args.workload}
+                                         for n in ("c2", "c4", "c4s", "mp", "g351", "ref1000_c3", "ref1000_g351")
+                                         if n != args.workload}
             if not args.no_c5_full and args.workload != "c5":
                 result["extra_workloads"]["c5_full_shard"] = c5_full_shard(A, ctx, seed)
             # what the reference's summation order costs on this workload (not on the streamed C5 shapes: N = 20 100 serial

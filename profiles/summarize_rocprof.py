@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 CSVs of one bench.py run (kernel trace + separate --pmc passes) into the small
-summaries committed under profiles/.  Usage (scripts/profile_round.sh does all of it on the GPU box):
-  python profiles/summarize_rocprof.py gpurun_out/prof_c3 r01_c3 c3
-Splits the fit launches of a step by kernel and grid size (phase A = starts, phase B = bootstraps: the largest grid).
-FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x
-(MI355X_MICROARCH.md §HBM), so hbm_bytes_per_launch = 2*FETCH + WRITE is an upper-side estimate here
-(this kernel's loads are 4- and 8-byte per lane, an uncalibrated width)."""
+"""Turns the rocprofv3 CSVs of one bench.py run (kernel trace + separate --pmc passes) into the small summaries committed
+under profiles/.  Usage (scripts/profile_round.sh does all of it on the GPU box):
+  python profiles/summarize_rocprof.py gpurun_out/prof_c3 r04_c3 c3 <repo root>
+Writes  <tag>_kernel_stats.csv, <tag>_rocprof_summary.json  and  <round>_pmc_<workload>.json: per PHASE of a step
+(fit_starts = the fit launches before the selection kernel, fit_boot = those after it — two phases may run the same
+kernel on the same grid, so the split is by dispatch order, not by name) the averages per launch of every counter
+collected, the HBM bytes derived from them and the content hash of the kernel sources they belong to (bench.py quotes
+them only for that very build).
+
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads
+(MI355X_MICROARCH.md §HBM): hbm_bytes_per_launch = 2 * FETCH + WRITE, as that section prescribes."""
 import collections
 import csv
+import datetime
 import glob
+import hashlib
 import json
+import os
 import shutil
 import sys
 from pathlib import Path
 
 src, tag, workload = Path(sys.argv[1]), sys.argv[2], sys.argv[3]
 out = Path(__file__).resolve().parent
-
-import os
+root = Path(sys.argv[4]) if len(sys.argv) > 4 else out.parent
 
 
 def newest(pattern):   # gpurun merges every run's files into the same directories: take the latest
@@ -25,56 +31,87 @@ def newest(pattern):   # gpurun merges every run's files into the same directori
     return max(files, key=os.path.getmtime) if files else None
 
 
+def phases_of(rows, name_key, order_key):
+    """[(phase, row)] for the fit launches of `rows` in dispatch order: fit_starts until a selection kernel has been seen,
+    fit_boot after it (abn_make_dstar_kernel belongs to phase B: it materialises the bootstrap observations); the fit
+    launch of phase B ends the step."""
+    state, out_rows = "fit_starts", []
+    for r in sorted(rows, key=lambda r: int(r[order_key])):
+        n = r[name_key]
+        if "abn_select" in n:
+            state = "fit_boot"
+        elif "abn_fit_" in n or "abn_make_dstar" in n:
+            out_rows.append((state, r))
+            if state == "fit_boot" and "abn_fit_" in n:
+                state = "fit_starts"
+    return out_rows
+
+
 stats = newest(str(src / "kt" / "*" / "*_kernel_stats.csv"))
-shutil.copy(stats, out / f"{tag}_kernel_stats.csv")
+if stats:
+    shutil.copy(stats, out / f"{tag}_kernel_stats.csv")
 
-trace = newest(str(src / "kt" / "*" / "*_kernel_trace.csv"))
-dur = collections.defaultdict(list)
-for r in csv.DictReader(open(trace)):
-    name = r["Kernel_Name"]
-    if "abn_fit_" in name:    # abn_fit_kernel / abn_fit_refill_kernel / abn_fit_spec_kernel
-        name += f" grid={r['Grid_Size_X']}"
-    dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 summary = {"workload": workload, "kernels": {}}
-for k, v in dur.items():
-    summary["kernels"][k] = {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
+trace = newest(str(src / "kt" / "*" / "*_kernel_trace.csv"))
+if trace:
+    rows = list(csv.DictReader(open(trace)))
+    dur = collections.defaultdict(list)
+    for r in rows:
+        name = r["Kernel_Name"]
+        if "abn_fit_" in name:    # abn_fit_kernel / abn_fit_refill_kernel / abn_fit_spec_kernel
+            name += f" grid={r['Grid_Size_X']}"
+        dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for k, v in dur.items():
+        summary["kernels"][k] = {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
+    ph = collections.defaultdict(list)
+    for p, r in phases_of(rows, "Kernel_Name", "Dispatch_Id"):
+        if "abn_fit_" in r["Kernel_Name"]:
+            ph[p].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    summary["fit_launch_avg_us_by_phase"] = {p: sum(v) / len(v) for p, v in ph.items()}
 
+# ---- counters, per phase
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
-    f = newest(str(src / d / "*" / "*_counter_collection.csv"))
+kern = {}
+for d in sorted(glob.glob(str(src / "pmc_*"))):
+    f = newest(d + "/*/*_counter_collection.csv")
     if not f:
         continue
-    for r in csv.DictReader(open(f)):
-        name = r["Kernel_Name"]
-        if "abn_fit_" in name:
-            name += f" grid={r['Grid_Size']}"
-        pmc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-summary["pmc_avg_per_launch"] = {k: {c: sum(x) / len(x) for c, x in v.items()} for k, v in pmc.items()}
-big = [k for k in summary["pmc_avg_per_launch"] if "abn_fit_" in k]   # phase B = the launch with the largest grid
-if big:
-    b = max(big, key=lambda k: int(k.split("grid=")[1]))
-    p = summary["pmc_avg_per_launch"][b]
-    if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
-        hbm = (2 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024
-        summary["phase_b_kernel"] = b
-        summary["hbm_bytes_per_launch"] = hbm
-        import datetime
-        import hashlib
+    rows = list(csv.DictReader(open(f)))
+    # one row per (dispatch, counter): split the dispatches into phases once per file
+    seen, disp = set(), []
+    for r in rows:
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
+            disp.append(r)
+    phase_of = {r["Dispatch_Id"]: p for p, r in phases_of(disp, "Kernel_Name", "Dispatch_Id")
+                if "abn_fit_" in r["Kernel_Name"]}
+    for r in rows:
+        p = phase_of.get(r["Dispatch_Id"])
+        if p:
+            pmc[p][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            kern[p] = f"{r['Kernel_Name']} grid={r['Grid_Size']}"
+summary["pmc_avg_per_launch"] = {p: {c: sum(x) / len(x) for c, x in v.items()} for p, v in pmc.items()}
 
-        h = hashlib.sha1()  # the same content hash bench.py computes: the figure belongs to these kernel sources
-        root = Path(sys.argv[4]) if len(sys.argv) > 4 else out.parent
-        for f in sorted((root / "alphabeta_rs_amd" / "csrc").glob("*")):
-            if f.name == "abn_multi.hip":   # as bench.py: device orchestration, no kernel
-                continue
-            if f.suffix in {".hip", ".hpp", ".h"}:
-                h.update(f.name.encode())
-                h.update(f.read_bytes())
-        (out / f"{tag.split('_')[0]}_pmc_fit_boot_{workload}.json").write_text(json.dumps(
-            {"workload": workload, "kernel": b, "FETCH_SIZE_KiB": p["FETCH_SIZE"], "WRITE_SIZE_KiB": p["WRITE_SIZE"],
-             "hbm_bytes_per_launch": hbm,
-             # wavefront-instruction counts of the same launch (SQ pass): the vector pipe issues one per SIMD every 4 cycles
-             **{k.lower() + "_per_launch": p[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES") if k in p},
-             "source_sha1": h.hexdigest(),
-             "collected": datetime.date.today().isoformat()}, indent=1))
+h = hashlib.sha1()  # the same content hash bench.py computes: the figures belong to these kernel sources
+for f in sorted((root / "alphabeta_rs_amd" / "csrc").glob("*")):
+    if f.name == "abn_multi.hip":   # as bench.py: device orchestration, no kernel
+        continue
+    if f.suffix in {".hip", ".hpp", ".h"}:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+phases = {}
+for p, c in summary["pmc_avg_per_launch"].items():
+    e = {"kernel": kern[p], **{k: v for k, v in c.items()}}
+    if "FETCH_SIZE" in c:
+        e["hbm_bytes_per_launch"] = (2 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024
+        e["hbm_bytes_has_write_pass"] = "WRITE_SIZE" in c
+    phases[p] = e
+if phases:
+    (out / f"{tag.split('_')[0]}_pmc_{workload}.json").write_text(json.dumps(
+        {"workload": workload, "phases": phases, "source_sha1": h.hexdigest(),
+         "units": "averages per launch; FETCH_SIZE / WRITE_SIZE in KiB, hbm_bytes = (2 FETCH + WRITE) x 1024 (gfx950 "
+                  "correction); SQ_ACTIVE_* / SQ_WAIT_* / SQ_WAVE_CYCLES / SQ_BUSY_CYCLES in quad-cycles summed over "
+                  "wavefronts (resp. SQs); SQ_INSTS_* in wavefront instructions",
+         "collected": datetime.date.today().isoformat()}, indent=1))
 (out / f"{tag}_rocprof_summary.json").write_text(json.dumps(summary, indent=1))
 print(json.dumps(summary, indent=1))
