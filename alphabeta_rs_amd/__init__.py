@@ -41,7 +41,7 @@ FIT_INFO_DTYPE = np.dtype(
 
 # every symbol include/abneutral.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
-    "abn_default_options", "abn_device_count", "abn_init", "abn_shutdown", "abn_last_error",
+    "abn_default_options", "abn_device_count", "abn_init", "abn_shutdown", "abn_device_info", "abn_last_error",
     "abn_status_string", "abn_version", "abn_cost_batch", "abn_fit_batch", "abn_gen_start_simplices",
     "abn_gen_boot_simplices", "abn_gen_boot_indices", "abn_ab_neutral_run", "abn_boot_model_run",
     "abn_analyze", "abn_select_best", "abn_bootstrap_rows", "abn_pairwise_divergence", "abn_plan_create", "abn_plan_destroy", "abn_plan_set_windows", "abn_plan_run",
@@ -100,6 +100,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     L.abn_device_count.argtypes = [C.POINTER(C.c_int)]
     L.abn_init.argtypes = [C.c_int, vp, C.POINTER(vp)]
     L.abn_shutdown.argtypes = [vp]
+    L.abn_device_info.argtypes = [vp, C.POINTER(C.c_int32)]
     L.abn_last_error.argtypes = [vp]
     L.abn_last_error.restype = C.c_char_p
     L.abn_status_string.argtypes = [C.c_int]
@@ -238,6 +239,13 @@ class Context:
         if getattr(self, "_h", None):
             self._L.abn_shutdown(self._h)
             self._h = None
+
+    def device_info(self):
+        """what abn_init read from hipDeviceProp and the persistent-launch geometry derived from it"""
+        out = (C.c_int32 * 4)()
+        self._check(self._L.abn_device_info(self._h, out))
+        return {"compute_units": out[0], "lds_kib_per_cu": out[1], "persistent_wavefronts": out[2],
+                "persistent_wavefronts_small": out[3]}
 
     def __enter__(self):
         return self

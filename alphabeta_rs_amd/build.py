@@ -14,7 +14,7 @@ PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libabneutral_hip.so"
 SOURCES = [CSRC / "abn_api.hip", CSRC / "abn_multi.hip"]
-DEPS = [CSRC / "abn_device.hpp", CSRC / "abn_pairwise_mx.hpp", CSRC / "abn_philox.h", PKG.parent / "include" / "abneutral.h"]
+DEPS = [*sorted(CSRC.glob("*.hpp")), CSRC / "abn_philox.h", PKG.parent / "include" / "abneutral.h"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

@@ -62,6 +62,10 @@ struct BufPool {
 
 struct abn_ctx {
   int device = -1;
+  // read from hipDeviceProp at abn_init (MI355X: 256 CUs, 160 KiB of LDS per CU); every launch geometry below is a
+  // multiple of the CU count, so a partitioned device (fewer CUs per logical GPU) gets proportionally smaller launches
+  int cus = 256;
+  size_t lds_per_cu = 160 * 1024;
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::vector<hipStream_t> side;  // lazily created: window groups of a plan run concurrently on these
@@ -214,24 +218,29 @@ static hipError_t allow_lds(const void* kernel, size_t lds) {
   return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 constexpr size_t kLdsResidentMax = 40 * 1024;
-#ifndef ABN_PERSIST_WAVES
-#define ABN_PERSIST_WAVES 3072
+// Launch geometry in wavefronts (or chains) PER CU; the totals in the comments are the MI355X's (256 CUs).
+#ifndef ABN_PERSIST_WAVES_PER_CU
+#define ABN_PERSIST_WAVES_PER_CU 12
 #endif
-constexpr long long kPersistWaves = ABN_PERSIST_WAVES;  // wavefronts of a persistent launch: 3 per SIMD x 4 SIMDs x 256 CUs
+constexpr long long kPersistWavesPerCu = ABN_PERSIST_WAVES_PER_CU;  // a persistent launch: 3 per SIMD x 4 SIMDs (3072)
 // A launch that would just about fill the resident wavefronts (2048 < wavefronts <= 3072: C3's 10 000 bootstraps are 2500)
 // runs persistent on 2048 of them instead: the last fifth of the chains waits in the queue, finished groups refill and
 // time slicing evens out the tail (C3 phase B 2.58 -> 2.44 ms; same box: 2.61 -> 2.53 ms, 1792 / 2304 wavefronts 2.71 /
 // 2.82 ms; profiles/r03_persist_waves_sweep.txt)
-#ifndef ABN_PERSIST_WAVES_SMALL
-#define ABN_PERSIST_WAVES_SMALL 2048
+#ifndef ABN_PERSIST_WAVES_SMALL_PER_CU
+#define ABN_PERSIST_WAVES_SMALL_PER_CU 8
 #endif
-constexpr long long kPersistWavesSmall = ABN_PERSIST_WAVES_SMALL;
-static long long persist_waves_for(long long blocks) { return blocks > kPersistWaves ? kPersistWaves : kPersistWavesSmall; }
-#ifndef ABN_PHASE_A_SPEC_MAX
-#define ABN_PHASE_A_SPEC_MAX 1024
+constexpr long long kPersistWavesSmallPerCu = ABN_PERSIST_WAVES_SMALL_PER_CU;
+static long long persist_waves(const abn_ctx* c) { return kPersistWavesPerCu * c->cus; }
+static long long persist_waves_small(const abn_ctx* c) { return kPersistWavesSmallPerCu * c->cus; }
+static long long persist_waves_for(const abn_ctx* c, long long blocks) {
+  return blocks > persist_waves(c) ? persist_waves(c) : persist_waves_small(c);
+}
+#ifndef ABN_PHASE_A_SPEC_PER_CU
+#define ABN_PHASE_A_SPEC_PER_CU 4
 #endif
-constexpr long long kPhaseASpecMax = ABN_PHASE_A_SPEC_MAX;  // start chains up to which phase A uses abn_fit_spec_kernel
-constexpr long long kPhaseAWideMax = 6144;  // ... and up to which it uses one wavefront per chain
+constexpr long long kPhaseASpecPerCu = ABN_PHASE_A_SPEC_PER_CU;  // start chains up to which phase A uses abn_fit_spec_kernel (1024)
+constexpr long long kPhaseAWidePerCu = 24;                      // ... and up to which it uses one wavefront per chain (6144)
 // Time slicing of persistent launches (FitArgs::quantum): evaluations a chain runs before it yields to waiting chains.
 #ifndef ABN_QUANTUM
 #define ABN_QUANTUM 256
@@ -358,14 +367,14 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, int* kin
   // More wavefronts than the GPU holds at once and several chains per wavefront: the persistent kernel, whose
   // groups take the next chain from a queue when their fit ends (abn_fit_refill_kernel)
   const bool refill = a.queue != nullptr && rmax > 0 && ng > 1 && a.iter_cap == 0 && a.resume == 0 &&
-                      blocks > kPersistWavesSmall;
-  if (refill) blocks = persist_waves_for(blocks);
+                      blocks > persist_waves_small(c);
+  if (refill) blocks = persist_waves_for(c, blocks);
   if (!refill) a.quantum = 0;
 #ifdef ABN_MEASUREMENT_KNOBS  // scripts/prio_sweep.sh: wave priority by chain age, wavefronts and quantum of the persistent launch
   if (refill) {
     if (const char* e = getenv("ABN_PRIO")) sscanf(e, "%d,%d,%d,%d", &a.prio_mode, &a.prio_t[0], &a.prio_t[1], &a.prio_t[2]);
     if (const char* e = getenv("ABN_PERSIST_WAVES_SMALL_ENV")) {
-      if (blocks == kPersistWavesSmall) blocks = std::max(64, atoi(e));
+      if (blocks == persist_waves_small(c)) blocks = std::max(64, atoi(e));
     }
     if (const char* e = getenv("ABN_QUANTUM_ENV")) {
       if (a.quantum > 0) a.quantum = std::max(16, atoi(e));
@@ -411,8 +420,9 @@ static bool fit_streams(int n, int chain_stride, int lanes, int strict) {
 // for pedigrees of up to two rows per lane, else two: the kernel's register budget).  Measured (scripts/phase_a_sweep.py,
 // C3 topology): 1000 chains 2.6 ms against 3.2 ms with one wavefront per chain, 1500 chains 4.2 against 3.4; the
 // 351-row golden pedigree with 1000 bootstraps: 2.8 ms against 2.0 ms.
-static long long spec_max_chains(int n_rows) {
-  return pick_rmax(n_rows, kWave) <= 2 ? kPhaseASpecMax : kPhaseASpecMax * 2 / 3;
+static long long spec_max_chains(const abn_ctx* c, int n_rows) {
+  const long long mx = kPhaseASpecPerCu * c->cus;
+  return pick_rmax(n_rows, kWave) <= 2 ? mx : mx * 2 / 3;
 }
 
 // a wavefront per chain runs the canonical tree (or, strict order, the serial sum) whenever the pedigree is LDS-resident
@@ -553,9 +563,17 @@ extern "C" int abn_init(int device_ordinal, void* stream, abn_ctx** out) {
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ABN_ERR_NO_DEVICE;
   if (device_ordinal < 0 || device_ordinal >= n) return ABN_ERR_INVALID_ARG;
   if (hipSetDevice(device_ordinal) != hipSuccess) return ABN_ERR_HIP;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return ABN_ERR_HIP;
+  // the library holds gfx950 code only, and its one-chain-per-workgroup kernels opt in to a CU's whole 160 KiB of LDS
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 || prop.multiProcessorCount <= 0 ||
+      (size_t)prop.maxSharedMemoryPerMultiProcessor < kMaxDynLds)
+    return ABN_ERR_NO_DEVICE;
   abn_ctx* c = new (std::nothrow) abn_ctx();
   if (!c) return ABN_ERR_HIP;
   c->device = device_ordinal;
+  c->cus = prop.multiProcessorCount;
+  c->lds_per_cu = (size_t)prop.maxSharedMemoryPerMultiProcessor;
   if (stream == ABN_STREAM_DEFAULT) {
     c->stream = nullptr;  // the null stream
     c->own_stream = false;
@@ -570,6 +588,15 @@ extern "C" int abn_init(int device_ordinal, void* stream, abn_ctx** out) {
     c->own_stream = true;
   }
   *out = c;
+  return ABN_OK;
+}
+
+extern "C" int abn_device_info(const abn_ctx* c, int32_t* out4) {
+  if (!c || !out4) return ABN_ERR_INVALID_ARG;
+  out4[0] = c->cus;
+  out4[1] = (int32_t)(c->lds_per_cu / 1024);
+  out4[2] = (int32_t)persist_waves(c);
+  out4[3] = (int32_t)persist_waves_small(c);
   return ABN_OK;
 }
 
@@ -648,7 +675,7 @@ static int launch_gen_idx(abn_ctx* c, uint32_t* idx, int n, int b, int w, uint64
   const long long total = (long long)w * b * ((n + 3) / 4);
   if (total <= 0) return ABN_OK;
   const long long want = (total + 255) / 256;
-  const unsigned blocks = (unsigned)std::min<long long>(want, 256LL * 32);
+  const unsigned blocks = (unsigned)std::min<long long>(want, 32LL * c->cus);
   hipLaunchKernelGGL(abn_gen_idx_kernel, dim3(blocks), dim3(256), 0, c->stream, idx, n, b, w, seed, woff, boff, wid);
   HIPCHK(c, hipGetLastError());
   return ABN_OK;
@@ -946,7 +973,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   // 8000 chains - / 7.7 / 7.0 ms)
   // The reduction tree stays the pedigree's (p->tree) whichever kernel runs: results do not depend on the size of
   // the launch, hence not on how a job is sharded over GPUs.
-  if (p->opt.lanes_per_chain == 0 && (long long)n_windows * n_starts <= kPhaseAWideMax &&
+  if (p->opt.lanes_per_chain == 0 && (long long)n_windows * n_starts <= kPhaseAWidePerCu * c->cus &&
       tree_on_wave_ok(n_rows, p->topo.chain_stride, p->tree, p->opt.strict_order))
     p->lanes_a = 64;
   // the footprint launch_fit will ask for when the pedigree is streamed (resident launches stay below kLdsResidentMax by
@@ -1002,7 +1029,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   }
   {  // time slicing for launches that outgrow the resident set of the persistent kernel (4 x kPersistWaves chains at 16 lanes)
     const size_t chains = W * std::max(S, B);
-    if (kQuantum > 0 && p->lanes < kWave && chains > (size_t)kPersistWavesSmall * (size_t)(kWave / p->lanes) &&
+    if (kQuantum > 0 && p->lanes < kWave && chains > (size_t)persist_waves_small(c) * (size_t)(kWave / p->lanes) &&
         chains * 32 * sizeof(double) <= kSliceStateMax && chains < (1u << 27) && p->opt.window_groups <= 1) {
       if (p->nm_state.n < chains * 32) PALLOC(nm_state, chains * 32);
       p->slice_cap = (unsigned)(chains * 16 / kParkShards + 4096);   // per shard; a full shard just stops parking
@@ -1154,7 +1181,7 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once,
   // a fourth keeps the simplex and prepares the next candidates meanwhile (abn_fit_spec_kernel)
   bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 &&
-              (long long)p->W * p->S <= spec_max_chains(p->N) && spec_applicable(a);
+              (long long)p->W * p->S <= spec_max_chains(c, p->N) && spec_applicable(a);
   int lanes_a = p->lanes_a;
 #ifdef ABN_MEASUREMENT_KNOBS  // ABN_PHASE_A_KERNEL = spec | wide | packed  (scripts/phase_a_sweep.py)
   if (const char* e = getenv("ABN_PHASE_A_KERNEL")) {
@@ -1261,7 +1288,7 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   if (p->stream_b) {  // gather the bootstrap observations once per fit, then stream them
     double* dst = p->dstar.p + o * B * N;
     const long long total = (long long)wn * p->B * p->N;
-    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 256LL * 64);
+    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 64LL * c->cus);
     hipLaunchKernelGGL(abn_make_dstar_kernel, dim3(blocks), dim3(256), 0, st, dst, a.pred, a.resid, a.idx, p->N,
                        (long long)p->B * p->N, total);
     HIPCHK(c, hipGetLastError());
@@ -1270,13 +1297,13 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   }
   // few bootstraps: latency-bound like phase A -> the speculative kernel (four wavefronts per chain)
   bool spec = a.dmode == 1 && p->opt.lanes_per_chain == 0 &&
-              (long long)p->W * p->B <= spec_max_chains(p->N) && spec_applicable(a);
+              (long long)p->W * p->B <= spec_max_chains(c, p->N) && spec_applicable(a);
   int lanes_b = p->lanes;
   // ... and up to 192 chains per packed lane (3072 for the 16-lane kernels) a wavefront per chain still beats packing
   // several chains into one (scripts/b_kernel_sweep.py, C3 topology: 2000 bootstraps 1.36 ms against 1.74 ms packed and
   // 1.81 ms speculative; 4000: 1.99 against 1.75; bundled 6-row pedigree, 8 lanes: 2000 bootstraps 1.98 against 1.90)
   if (!spec && a.dmode == 1 && p->opt.lanes_per_chain == 0 && p->lanes < kWave &&
-      (long long)p->W * p->B <= 192LL * p->lanes && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree, p->opt.strict_order))
+      (long long)p->W * p->B <= (3LL * c->cus / 4) * p->lanes && tree_on_wave_ok(p->N, p->topo.chain_stride, p->tree, p->opt.strict_order))
     lanes_b = kWave;
 #ifdef ABN_MEASUREMENT_KNOBS  // ABN_PHASE_B_KERNEL = spec | wide | packed
   if (const char* e = getenv("ABN_PHASE_B_KERNEL")) {
@@ -1746,7 +1773,7 @@ static int pairwise_mx_family(abn_ctx* c, PairMxArgs a, bool diag, long long nsp
   // chunks per super-pair: enough jobs to fill the GPU (cu_jobs workgroups per CU), every wavefront at least a few K
   // steps of 64 sites, and no chunk beyond 2^30 sites (the packed 32-bit halves of a job's sums)
   const long long nk = (a.L + 63) / 64;
-  long long nchunks = std::max<long long>(1, (256 * cu_jobs + nsp - 1) / nsp);
+  long long nchunks = std::max<long long>(1, ((long long)c->cus * cu_jobs + nsp - 1) / nsp);
   nchunks = std::min<long long>(nchunks, std::max<long long>(1, nk / (4 * kPmxWaves)));
   nchunks = std::max<long long>(nchunks, (a.L >> 30) + 1);
   if (a.L == 0) nchunks = 1;

@@ -1,0 +1,552 @@
+// abn_fit_spec_kernel: four wavefronts per chain (three speculative evaluations + the keeper) for latency-bound launches.
+#pragma once
+#include "abn_common.hpp"
+
+namespace abn {
+
+// ------------------------------------------------------------------------------------------------
+// Speculative fit kernel for the latency-bound case (few chains: the S starts of phase A, a few hundred bootstraps).
+// A Nelder-Mead iteration evaluates the reflection and then, depending on its cost, the expansion OR the
+// contraction point (argmin next_iter) — two dependent evaluations on ~70 % of the iterations.  All three
+// candidates are known before the first cost: x_r = x0 + (x0 - x_w), x_e = x0 + 2 (x_r - x0),
+// x_c = x0 + (x_w - x0)/2.  Here a chain owns a workgroup of FOUR wavefronts, one per SIMD of a CU:
+//   * wavefronts 0..2 evaluate one candidate each with the G = 64 tree and exchange the three costs through
+//     LDS.  They hold no optimiser state: behind the exchange barrier they read the sorted costs of the previous
+//     update and a done flag (published by the keeper), take the reference's decision — which point is accepted
+//     and at which rank it sorts in: one of ten outcomes — and pick their next candidate, its generation-matrix
+//     elements (matrix-instruction layout) and its penalty term out of tables.
+//   * wavefront 3, the "keeper", alone holds the simplex (dimension per lane), costs, best vertex and counters.
+//     While the others evaluate the candidates of iteration i it works out, for each of the ten outcomes (one per
+//     quad of lanes), the three candidates of iteration i+1 and what depends on their (alpha, beta) only, and
+//     publishes the costs / done flag of the update it made after iteration i-1.
+// The done flag reaches the evaluation wavefronts one evaluation late (a finished fit costs one surplus evaluation,
+// never counted); every wavefront derives its control flow from the same published numbers, so they reach the
+// same barriers.  Results, iteration and evaluation counts (only evaluations the reference would have made are
+// counted) are bit-identical to abn_fit_kernel<64,*>.
+// Resident mode only (N <= 64*RMAX).  LDS: 3 x chain_stride doubles + kSpecCommDoubles.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_lds_fence() {  // orders this wavefront's LDS writes before its reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+constexpr int kSpecOutcomes = 10;                                   // r@0..3, e@0, c@0..4
+constexpr int kSpecTabDoubles = kSpecOutcomes * 12;                 // [outcome][candidate r/e/c][dimension]
+constexpr int kSpecPreDoubles = kSpecOutcomes * 3 * 12;             // [outcome][candidate][G (9), penalty, 0.0, pad]
+constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16 + 2 * kSpecPreDoubles + 16;  // cost exchange, two candidate
+                                                 // tables, shrink points, two tables of prepared inputs, two control blocks
+
+// STRICT (abn_options.strict_order): the evaluation wavefronts sum the residuals serially in row order (terms to LDS, N
+// more doubles per wavefront, then serial_sum_lds) — the reference's order, the oracle's lanes = 1.
+template <int RMAX, bool STRICT = false>
+__global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_kernel(const FitArgs a) {
+  constexpr int G = kWave;
+  extern __shared__ __align__(16) double lds[];
+  const int wv = threadIdx.x >> 6;      // 0: reflection, 1: expansion, 2: contraction, 3: keeper
+  const int gl = threadIdx.x & 63;
+  const int dim = gl & 3;
+  const bool keeper = wv == 3;
+  const long long chain = blockIdx.x;   // grid = W*C exactly
+  const int w = (int)(chain / a.C);
+  const int N = a.N, K = a.K, TP = a.TP;
+
+  double* pw = lds + (size_t)(keeper ? 0 : wv) * a.chain_stride;  // the keeper never touches its alias
+  double* dtab = pw + kPw * TP;
+  double* wconst = dtab + ((K + 1) & ~1);
+  double* dobs = wconst + 4;
+  double* xch = lds + (size_t)3 * a.chain_stride;  // two buffers of 3 costs (+ pad)
+  double* tab = xch + 8;                           // two candidate tables
+  double* pts = tab + 2 * kSpecTabDoubles;         // NelderMead::shrink: the four moved vertices
+  double* gtab = pts + 16;                         // per candidate: generation matrix, penalty term, a zero
+
+  const int wi = w * a.wstride;
+  const size_t wN = (size_t)w * (size_t)N;
+  uint32_t triv[RMAX], tidp[(RMAX + 1) / 2];
+#pragma unroll
+  for (int q = 0; q < (RMAX + 1) / 2; ++q) tidp[q] = 0u;
+#pragma unroll
+  for (int q = 0; q < RMAX; ++q) triv[q] = 0u;
+  // keeper state: the simplex, this lane's dimension of the five vertices in rank order
+  double vx[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  if (!keeper) {
+    if (gl == 0) {
+      const double p_uu0 = a.p_uu[wi];
+      wconst[0] = p_uu0;
+      wconst[1] = 1.0 - p_uu0;
+      wconst[2] = a.eqp[wi];
+      wconst[3] = a.eqp_w[wi] * (double)N;
+    }
+    const uint32_t* idx_row = (a.dmode == 1) ? a.idx + (size_t)chain * (size_t)N : nullptr;
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const int i = gl + G * q;
+      triv[q] = (i < K) ? a.tri[i] : 0u;
+      if (i < N) {
+        tidp[q / 2] |= (uint32_t)a.tid[i] << (16 * (q & 1));
+        dobs[i] = (a.dmode == 1) ? a.pred[wN + i] + a.resid[wN + idx_row[i]]  // src/boot_model.rs:50-54
+                                 : a.D[wN + i];
+      }
+    }
+  } else {
+    // start simplex (starts: given; bootstraps: [params, vary() x4], src/boot_model.rs:69-75), handed to the
+    // evaluation wavefronts through the (still unused) candidate table
+    if (a.smode == 0) {
+      const double* s0 = a.simplex0 + (size_t)chain * 20;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) vx[k] = s0[4 * k + dim];
+    } else {
+      const int j = (int)(chain - (long long)w * a.C);
+      const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
+      const uint32_t wg = a.wid ? a.wid[w] : a.window_offset + (uint32_t)w, bg = a.boot_offset + (uint32_t)j;
+      vx[0] = a.model[4 * w + dim];
+#pragma unroll
+      for (int v = 1; v < 5; ++v) {
+        uint32_t r[4];
+        philox4x32_10((uint32_t)(v - 1) * 2u + (uint32_t)(dim >> 1), bg, wg, kTagJitter, k0, k1, r);
+        const uint32_t r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        const bool odd = (dim & 1) != 0;
+        vx[v] = vary_one(vx[0], odd ? r2 : r0, odd ? r3 : r1);
+      }
+    }
+    if (gl < 4) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) tab[4 * k + dim] = vx[k];
+    }
+  }
+  __syncthreads();
+
+#ifdef ABN_STAMPS
+  unsigned long long seg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+#endif
+  // Inputs of the next evaluation that depend on (alpha, beta) only and that the keeper prepares next to the
+  // candidate (kMatrixFma builds): this lane's elements of G^T and G in the matrix-instruction layout, the
+  // equilibrium penalty term.  `pre` = they are valid for the candidate being evaluated.
+  double preA = 0.0, preB = 0.0, prePen = 0.0;
+  const int mx_x = gl & 3, mx_y = gl >> 4;
+  const bool mx_in = (mx_x < 3) && (mx_y < 3) && (((gl >> 2) & 3) == 0);
+  const int preA_idx = mx_in ? 3 * mx_y + mx_x : 10, preB_idx = mx_in ? 3 * mx_x + mx_y : 10;  // [10] holds 0.0
+  auto eval = [&](double xd, bool pre) -> double {
+    ABN_STAMP(6);  // control flow + candidate fetch since the exchange
+    const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
+    const double p_mm = wconst[1];
+    const double sv0 = wconst[0], sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;
+    double pen;
+    if (kMatrixFma && pre) {
+      pen = prePen;
+      ABN_STAMP(0);
+      build_power_table_mx_pre(preA, preB, a.T, pw, dtab, gl);
+    } else {
+      const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
+      const double puu = p_uu_est(al, be);
+      const double dq = puu - wconst[2];
+      pen = wconst[3] * (dq * dq);
+      ABN_STAMP(0);
+      if constexpr (kMatrixFma) build_power_table_mx<G>(al, be, a.T, pw, 0, dtab, gl);  // one chain per wavefront: block 0
+      else build_power_table<G>(genmatrix(al, be), a.T, TP, pw, gl);
+    }
+    wave_lds_fence();
+    ABN_STAMP(1);
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const int t = gl + G * q;
+      if (t < K) dtab[t] = triple_dt(triv[q], pw, TP, sv0, sv1, sv2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    wave_lds_fence();
+    ABN_STAMP(2);
+    double acc = 0.0;
+    double dv[RMAX], tv[RMAX];
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const bool in = (gl + G * q) < N;
+      dv[q] = in ? dobs[gl + G * q] : 0.0;
+      tv[q] = in ? dtab[(tidp[q / 2] >> (16 * (q & 1))) & 0xffffu] : 0.0;
+    }
+    if constexpr (STRICT) {   // `square_sum += ...` in row order, src/structs.rs:206-213
+      if (RMAX == 1 && N <= 16) {   // one row per lane, at most 16 rows: the sum through lane reads (wavefront-uniform branch)
+        const double r = dv[0] - ic - tv[0];
+        acc = serial_sum_lanes16(gl < N ? r * r + pen : 0.0, N);
+      } else {
+        double* term = dobs + ((N + 1) & ~1);
+#pragma unroll
+        for (int q = 0; q < RMAX; ++q) {
+          if ((gl + G * q) < N) {
+            const double r = dv[q] - ic - tv[q];
+            term[gl + G * q] = r * r + pen;
+          }
+        }
+        wave_lds_fence();
+        acc = serial_sum_lds(term, N, 0.0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < RMAX; ++q) {
+        if ((gl + G * q) < N) {
+          const double r = dv[q] - ic - tv[q];
+          acc = acc + (r * r + pen);
+        }
+      }
+      // P5: the canonical tree (without strict order this kernel runs under auto options only: FitArgs::tree == kTreeCanon)
+      const double one[1] = {acc};
+      acc = tree64_finish<G>(one);
+    }
+    wave_lds_fence();
+    ABN_STAMP(3);
+    return acc;
+  };
+
+  // exchange: every evaluation wavefront publishes its cost, one workgroup barrier, everybody reads all three.
+  // The barrier also hands the keeper's LDS writes (candidate table, shrink points) to the others.
+  int phase = 0;
+  auto exchange = [&](double f, double& f0, double& f1, double& f2) {
+    double* buf = xch + 4 * phase;
+    if (!keeper && gl == 0) buf[wv] = f;
+    __syncthreads();
+    f0 = buf[0];
+    f1 = buf[1];
+    f2 = buf[2];
+    phase ^= 1;  // the other buffer next time: no second barrier needed
+    ABN_STAMP(4);
+  };
+
+  // ---- control state (the keeper's; the evaluation wavefronts hold a published copy of the costs in c[])
+  double c[5], best_cost = __builtin_inf();
+  bool have_best = false;
+  int iter = 0;
+  // IterState::update() + terminate_internal(): -1 = go on, else the ABN_FIT_* status.  `improved`: the best
+  // vertex is the new best_param (the keeper copies it)
+  auto ctl_begin = [&](bool count_iter, bool& improved) -> int {
+    const double c_best = c[0];
+    improved = c_best < best_cost || (__builtin_isinf(c_best) && __builtin_isinf(best_cost) &&
+                                      (__builtin_signbit(c_best) == __builtin_signbit(best_cost)));
+    best_cost = improved ? c_best : best_cost;
+    have_best = have_best || improved;
+    if (count_iter) ++iter;
+    bool converged = false;
+    if (!((c[4] - c[0]) > a.gap_tol)) {
+      double sum = 0.0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) sum = sum + c[k];
+      const double c0 = sum / 5.0;
+      double ss = 0.0;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) ss = ss + (c[k] - c0) * (c[k] - c0);
+      const double sd = __builtin_sqrt(1.0 / (5.0 - 1.0) * ss);
+      converged = sd < a.sd_tol;
+    }
+    int status = -1;
+    if (converged) status = 0;
+    else if (iter >= a.max_iters) status = 1;
+    else if (best_cost <= -__builtin_inf()) status = 3;
+    return status;
+  };
+
+  // ---- keeper state: the simplex, this lane's dimension of the five vertices in rank order, the three
+  // candidates of the running iteration, best_param, evaluation count
+  double xr = 0.0, x_e = 0.0, x_c = 0.0, bx = __builtin_nan("");
+  int evals = 0;
+  // the keeper's lane group: quad q < 10 works on outcome q = (accepted point, rank): r@0..3, e@0, c@0..4
+  const int oq = gl >> 2;
+  const int o_kind = oq < 4 ? 0 : (oq == 4 ? 1 : 2);
+  const int o_rank = oq < 4 ? oq : (oq == 4 ? 0 : oq - 5);
+
+  // keeper: generation matrix and penalty term of the three candidates (r_, e_, c_: this lane's dimension) of
+  // outcome slot `oq` — lane (quad, dimension t < 3) works for candidate t; same functions as the evaluation
+  // wavefronts would call, so the same bits
+  auto emit_pre = [&](double r_, double e_, double c_, int parity) {
+    const double ar = dpp_mov<kDppQuadBcast0>(r_), br = dpp_mov<kDppQuadBcast1>(r_);
+    const double ae = dpp_mov<kDppQuadBcast0>(e_), be = dpp_mov<kDppQuadBcast1>(e_);
+    const double ac = dpp_mov<kDppQuadBcast0>(c_), bc = dpp_mov<kDppQuadBcast1>(c_);
+    const double al_t = dim == 0 ? ar : (dim == 1 ? ae : ac);
+    const double be_t = dim == 0 ? br : (dim == 1 ? be : bc);
+    const Gen Gt = genmatrix(al_t, be_t);
+    const double puu = p_uu_est(al_t, be_t);
+    const double dq = puu - wconst[2];
+    const double pen = wconst[3] * (dq * dq);
+    if (oq < kSpecOutcomes && dim < 3) {
+      double* g = gtab + parity * kSpecPreDoubles + (oq * 3 + dim) * 12;
+      g[0] = Gt.g0;
+      g[1] = Gt.g1;
+      g[2] = Gt.g2;
+      g[3] = Gt.g3;
+      g[4] = Gt.g4;
+      g[5] = Gt.g5;
+      g[6] = Gt.g6;
+      g[7] = Gt.g7;
+      g[8] = Gt.g8;
+      g[9] = pen;
+      g[10] = 0.0;
+    }
+  };
+  // evaluation wavefronts: the prepared inputs of candidate (outcome o, this wavefront) next to the candidate itself
+  auto fetch_pre = [&](int o, int parity) {
+    const double* g = gtab + parity * kSpecPreDoubles + (o * 3 + wv) * 12;
+    preA = g[preA_idx];
+    preB = g[preB_idx];
+    prePen = g[9];
+  };
+
+  // ---- The keeper alone keeps the optimiser's state.  What the evaluation wavefronts need to follow the control
+  // flow it publishes in `ctl` (two buffers): the five sorted costs BEFORE the running iteration (their decision
+  // needs c0, c3, c4 and the rank of the accepted cost) and a `done` flag.  The keeper writes ctl[cb] while the
+  // others evaluate; they read it behind the next exchange barrier, then everybody flips cb.  The flag therefore
+  // reaches them one evaluation late: a finished fit costs one surplus evaluation (never counted, never used),
+  // every iteration saves the cost insertion and the termination test on the evaluation wavefronts' path.
+  double* ctl = gtab + 2 * kSpecPreDoubles;
+  int cb = 0;
+  auto ctl_write = [&](int status_now) {      // keeper
+    if (gl < 5) ctl[8 * cb + gl] = gl == 0 ? c[0] : (gl == 1 ? c[1] : (gl == 2 ? c[2] : (gl == 3 ? c[3] : c[4])));
+    if (gl == 5) ctl[8 * cb + 5] = status_now >= 0 ? 1.0 : 0.0;
+  };
+  bool improved;
+  int status = -1;
+  int par = 0;
+  double f0, f1, f2;
+  double cand = 0.0;
+
+  // hand-over of a freshly sorted simplex (after Solver::init and after a shrink): the keeper writes the control
+  // block and, unless the fit is finished, the three candidates with their prepared inputs; one barrier; the
+  // evaluation wavefronts learn `done` and pick their candidate up.  Returns done.
+  auto publish = [&]() -> bool {
+    if (keeper) {
+      ctl_write(status);
+      if (status < 0) {  // centroid (p0 + p1 + p2 + p3) * (1/4), x0 + (x0 - xw) * alpha, x0 + (xr - x0) * gamma, x0 + (xw - x0) * rho
+        double acc = vx[0];
+        acc = acc + vx[1];
+        acc = acc + vx[2];
+        acc = acc + vx[3];
+        const double x0 = acc * (1.0 / 4.0);
+        xr = x0 + (x0 - vx[4]) * 1.0;
+        x_e = x0 + (xr - x0) * 2.0;
+        x_c = x0 + (vx[4] - x0) * 0.5;
+        if (gl < 4) {
+          double* t = tab + par * kSpecTabDoubles;
+          t[dim] = xr;
+          t[4 + dim] = x_e;
+          t[8 + dim] = x_c;
+        }
+        if constexpr (kMatrixFma) emit_pre(xr, x_e, x_c, par);  // every quad writes its slot; slot 0 is read
+      }
+    }
+    __syncthreads();
+    bool done = status >= 0;                  // keeper
+    if (!keeper) {
+      done = ctl[8 * cb + 5] != 0.0;
+      if (!done) {
+        cand = tab[par * kSpecTabDoubles + 4 * wv + dim];
+        if constexpr (kMatrixFma) fetch_pre(0, par);
+      }
+    }
+    par ^= 1;
+    return done;
+  };
+
+  // ---- Solver::init: the five start costs in input order (3 + 2), stable sort, first termination check
+  cand = keeper ? 0.0 : tab[4 * wv + dim];
+  exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
+  c[0] = f0;
+  c[1] = f1;
+  c[2] = f2;
+  cand = keeper ? 0.0 : tab[4 * (wv == 0 ? 3 : 4) + dim];
+  exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
+  c[3] = f0;
+  c[4] = f1;
+  evals = 5;
+  if (keeper) {
+    sort5(c, vx);
+    status = ctl_begin(false, improved);
+    if (improved) bx = vx[0];
+  }
+  bool done = publish();
+
+  while (!done) {
+    if (keeper) {
+      // the candidates of the NEXT iteration for each way this one can end.  Outcome (A, p): the accepted
+      // point A replaces the worst vertex and sorts in at rank p; the new order is v0..v3 with A at p.
+      const double A = o_kind == 0 ? xr : (o_kind == 1 ? x_e : x_c);
+      const double e0 = o_rank == 0 ? A : vx[0];
+      const double e1 = o_rank == 1 ? A : (o_rank < 1 ? vx[0] : vx[1]);
+      const double e2 = o_rank == 2 ? A : (o_rank < 2 ? vx[1] : vx[2]);
+      const double e3 = o_rank == 3 ? A : (o_rank < 3 ? vx[2] : vx[3]);
+      const double xw = o_rank == 4 ? A : vx[3];
+      double acc = e0;
+      acc = acc + e1;
+      acc = acc + e2;
+      acc = acc + e3;
+      const double x0 = acc * (1.0 / 4.0);
+      const double nr = x0 + (x0 - xw) * 1.0;
+      const double ne = x0 + (nr - x0) * 2.0;
+      const double nc = x0 + (xw - x0) * 0.5;
+      if (oq < kSpecOutcomes) {
+        double* t = tab + par * kSpecTabDoubles + oq * 12;
+        t[dim] = nr;
+        t[4 + dim] = ne;
+        t[8 + dim] = nc;
+      }
+      if constexpr (kMatrixFma) emit_pre(nr, ne, nc, par);
+    }
+    double fr, fe, fc;
+    {  // exchange + (evaluation wavefronts) the control block, read in ONE batch of LDS loads behind the barrier:
+       // the sorted costs before this iteration, and whether the keeper finished the fit while this (then surplus)
+       // evaluation ran
+      const double f = keeper ? 0.0 : eval(cand, true);
+      double* buf = xch + 4 * phase;
+      if (!keeper && gl == 0) buf[wv] = f;
+      __syncthreads();
+      const double* b = ctl + 8 * cb;
+      fr = buf[0];
+      fe = buf[1];
+      fc = buf[2];
+      double k0 = c[0], k1 = c[1], k2 = c[2], k3 = c[3], k4 = c[4], dn = 0.0;
+      if (!keeper) {
+        k0 = b[0];
+        k1 = b[1];
+        k2 = b[2];
+        k3 = b[3];
+        k4 = b[4];
+        dn = b[5];
+      }
+      c[0] = k0;
+      c[1] = k1;
+      c[2] = k2;
+      c[3] = k3;
+      c[4] = k4;
+      phase ^= 1;
+      ABN_STAMP(4);
+#ifdef ABN_STAMPS
+      ++seg[7];  // iterations seen by this wavefront
+#endif
+      if (dn != 0.0) break;
+    }
+    cb ^= 1;
+    // ---- NelderMead::next_iter's decision.  Every lane holds the same costs, so the branches are uniform.
+    // (Measured alternatives, all slower on a lone wavefront: the costs in scalar registers via v_readfirstlane —
+    // persistent: SGPR spills; re-read every iteration: +23 % —, and the flat predicated form of abn_fit_kernel.)
+    int kind, which = 0;   // kind 0: a point is accepted, 1: rejected contraction (simplex untouched), 2: shrink
+    double fi = fr;
+    int spent;             // cost() calls the reference makes in this branch
+    if (fr < c[3] && fr >= c[0]) {          // reflection accepted
+      kind = 0;
+      spent = 1;
+    } else if (fr < c[0]) {                 // expansion tried
+      kind = 0;
+      spent = 2;
+      const bool take_e = fe < fr;
+      which = take_e ? 1 : 0;
+      fi = take_e ? fe : fr;
+    } else if (fr >= c[3]) {                // contraction tried
+      spent = 2;
+      if (fc < c[4]) {
+        kind = 0;
+        which = 2;
+        fi = fc;
+      } else {
+        kind = a.shrink_variant ? 2 : 1;
+      }
+    } else {                                // NaN reflection cost
+      kind = 2;
+      spent = 1;
+    }
+    evals += spent;
+    if (kind == 0) {
+      // rank of the accepted point: the stable insertion of insert_tail<4>
+      const bool b3 = fi < c[3], b2 = b3 && (fi < c[2]), b1 = b2 && (fi < c[1]), b0 = b1 && (fi < c[0]);
+      const int p = 4 - ((b3 ? 1 : 0) + (b2 ? 1 : 0) + (b1 ? 1 : 0) + (b0 ? 1 : 0));
+      const int o = which == 0 ? p : (which == 1 ? 4 : 5 + p);
+      const double* t = tab + par * kSpecTabDoubles + o * 12;
+      if (keeper) {
+        c[4] = fi;
+        vx[4] = which == 0 ? xr : (which == 1 ? x_e : x_c);
+        insert_tail<4>(c, vx);
+        status = ctl_begin(true, improved);
+        if (improved) bx = vx[0];
+        ctl_write(status);
+        xr = t[dim];
+        x_e = t[4 + dim];
+        x_c = t[8 + dim];
+      } else {
+        cand = t[4 * wv + dim];
+        if constexpr (kMatrixFma) fetch_pre(o, par);
+        ABN_STAMP(5);  // decision
+      }
+      par ^= 1;
+    } else if (kind == 1) {
+      // argmin 0.8.1: a rejected contraction leaves the simplex untouched — for good: every later iteration
+      // repeats this one.  no_skip == 0: finish the chain with the counters it would reach (FitArgs::no_skip)
+      if (keeper) {
+        if (a.no_skip == 0) {
+          const int rest = a.max_iters - iter - 1;
+          evals += 2 * rest;
+          iter += rest;
+          if (a.skipped && gl == 0 && rest > 0) atomicAdd(a.skipped, 2ull * (unsigned long long)rest);
+        }
+        status = ctl_begin(true, improved);
+        ctl_write(status);
+      }
+      par ^= 1;  // same candidates again; the keeper rebuilds the (identical) tables in the other buffers
+    } else {
+      // NelderMead::shrink (NaN reflection cost, or the textbook variant after a rejected contraction):
+      // vertices 1..4 move towards the best by sigma and are re-evaluated in order (3 + 1)
+      if (keeper) {
+#pragma unroll
+        for (int k = 1; k < 5; ++k) {
+          vx[k] = vx[0] + (vx[k] - vx[0]) * 0.5;
+          if (gl < 4) pts[4 * (k - 1) + dim] = vx[k];
+        }
+      }
+      __syncthreads();
+      if (!keeper) cand = pts[4 * wv + dim];
+      exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
+      c[1] = f0;
+      c[2] = f1;
+      c[3] = f2;
+      if (!keeper) cand = pts[12 + dim];
+      exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
+      c[4] = f0;
+      evals += 4;
+      if (keeper) {
+        sort5(c, vx);
+        status = ctl_begin(true, improved);
+        if (improved) bx = vx[0];
+      }
+      done = publish();
+      continue;
+    }
+    // the keeper found the fit finished: the others are one evaluation ahead — meet them at that exchange
+    if (keeper && status >= 0) {
+      exchange(0.0, f0, f1, f2);
+      break;
+    }
+  }
+
+#ifdef ABN_STAMPS
+  if (a.dbg && chain == 0 && wv == 0 && gl == 0) {
+    for (int q = 0; q < 8; ++q) a.dbg[q] = seg[q];
+    a.dbg[7] = seg[7];
+  }
+#endif
+  const double b0 = dpp_mov<kDppQuadBcast0>(bx), b1 = dpp_mov<kDppQuadBcast1>(bx);
+  if (keeper) {
+    if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
+    if (gl == 0) {
+      FitInfoDev fo;
+      fo.best_cost = best_cost;
+      fo.iters = iter;
+      fo.evals = evals;
+      fo.status = have_best ? status : 2;
+      fo.lanes = a.tree;
+      a.info[chain] = fo;
+    }
+    if (a.raw) {
+      double* ro = a.raw + (size_t)chain * 7;
+      if (gl < 4) ro[gl] = bx;
+      if (gl == 4) ro[4] = est_mm(b0, b1);
+      if (gl == 5) ro[5] = est_um(b0, b1);
+      if (gl == 6) ro[6] = p_uu_est(b0, b1);
+    }
+  }
+}
+
+}  // namespace abn

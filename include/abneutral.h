@@ -104,6 +104,11 @@ int abn_init(int device_ordinal, void* stream, abn_ctx** ctx);
 /* Frees the context and its device-buffer pool (the per-call entry points recycle their device buffers through it
  * instead of hipMalloc / hipFree per call).  Destroy the context's plans first. */
 int abn_shutdown(abn_ctx* ctx);
+/* What abn_init read from hipDeviceProp and the launch geometry derived from it: out4 = {compute units, KiB of LDS per
+ * CU, wavefronts of a persistent fit launch, wavefronts of a persistent launch that just about fills the GPU}.  MI355X:
+ * {256, 160, 3072, 2048}.  abn_init refuses (ABN_ERR_NO_DEVICE) a device that is not gfx950 or has less LDS per CU.
+ * (The reference has no counterpart: rayon sizes its pool from the host's cores, src/ab_neutral.rs:37, src/boot_model.rs:41.) */
+int abn_device_info(const abn_ctx* ctx, int32_t* out4);
 const char* abn_last_error(const abn_ctx* ctx);
 const char* abn_status_string(int status);
 int abn_version(void);

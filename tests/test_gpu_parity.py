@@ -833,6 +833,13 @@ def test_persistent_refill_kernel_is_schedule_independent(abn, gpu_ctx, golden, 
             assert np.array_equal(out["info_b"][w][k], res[k]), k
 
 
+def test_device_geometry_is_read_from_the_device_and_is_the_mi355x(abn, gpu_ctx):
+    """VERDICT r03 hygiene: CU count and LDS size come from hipDeviceProp at abn_init (launch geometry = multiples of the CU
+    count), asserted here to be the MI355X's: 256 CUs, 160 KiB of LDS per CU, 3072 / 2048 persistent wavefronts."""
+    assert gpu_ctx.device_info() == {"compute_units": 256, "lds_kib_per_cu": 160, "persistent_wavefronts": 3072,
+                                     "persistent_wavefronts_small": 2048}
+
+
 def test_lost_fifo_entry_is_an_error_at_sync(abn):
     """a parked chain whose FIFO entry never appears must not end as uninitialised rows under ABN_OK on
     the paths that never call abn_plan_download — the torch.distributed shard runner reads a bound buffer after
