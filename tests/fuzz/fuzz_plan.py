@@ -5,6 +5,7 @@ import sys, time
 from pathlib import Path
 import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+sys.path.insert(0, str(Path(__file__).resolve().parent))   # fuzz_parity, when loaded from tests/test_gpu_fuzz_slice.py
 import alphabeta_rs_amd as A
 import oracle as O
 from fuzz_parity import rand_ped

@@ -31,7 +31,9 @@ def test_bench_json_contract():
     assert "traffic_source" in ro and (ro["traffic"] is None or ro["traffic_source"].get("source_sha1"))
     # round 2: the PCIe-inclusive rate, short runs of the other BASELINE configurations and the pairwise scan ride along
     assert j["pcie_inclusive"]["fits_per_s"] > 1e5 and j["pcie_inclusive"]["fits_per_s"] < j["value"] * 1.05
-    assert set(j["extra_workloads"]) == {"c2", "c4", "g351", "ref1000_c3", "ref1000_g351"}   # (--no-c5-full below)
+    assert set(j["extra_workloads"]) == {"c2", "c4", "c4s", "mp", "g351", "ref1000_c3", "ref1000_g351"}   # (--no-c5-full)
+    mp = j["extra_workloads"]["mp"]                    # the reference's default metaprofile shape, phase split and skipped evaluations
+    assert set(mp["kernel_ms"]) == {"fit_starts", "select", "fit_boot"} and "evals_not_executed" in mp
     assert all(w["fits_per_s"] > 1e4 for w in j["extra_workloads"].values())
     # round 3: the reference's default shape (1000 starts + 1000 bootstraps) with its phase split, kernels and stuck fits
     for n in ("ref1000_c3", "ref1000_g351"):
