@@ -40,9 +40,10 @@ misc)
   timeout -k 10 300 python bench.py --gpus 2 --steps 2 > $out/bench_gpus2_nccl.out 2> $out/bench_gpus2_nccl.err; echo "nccl --gpus 2 on a one-GPU box: rc=$? (must be non-zero, no JSON)"
   echo "== stream-mode working-set sweep"
   BENCH_TIMEOUT=900 run_bench stream_sweep --stream-sweep --no-extras --no-cpu-baseline --steps 5
-  echo "== fuzz (2 x 150 s) and soak on the final kernels"
-  timeout -k 10 200 python tests/fuzz/fuzz_parity.py 150 404 > $out/fuzz_parity.log 2>&1; tail -1 $out/fuzz_parity.log
-  timeout -k 10 200 python tests/fuzz/fuzz_plan.py 150 405 > $out/fuzz_plan.log 2>&1; tail -1 $out/fuzz_plan.log;;
+  echo "== fuzz (2 x ${FUZZ_S:-400} s) and soak (${SOAK_S:-300} s) on the final kernels"
+  timeout -k 10 $((${FUZZ_S:-400} + 60)) python tests/fuzz/fuzz_parity.py ${FUZZ_S:-400} 404 > $out/fuzz_parity.log 2>&1; tail -1 $out/fuzz_parity.log
+  timeout -k 10 $((${FUZZ_S:-400} + 60)) python tests/fuzz/fuzz_plan.py ${FUZZ_S:-400} 405 > $out/fuzz_plan.log 2>&1; tail -1 $out/fuzz_plan.log
+  timeout -k 10 $((${SOAK_S:-300} + 120)) python tests/fuzz/soak_timeslice.py ${SOAK_S:-300} > $out/soak.log 2>&1; tail -3 $out/soak.log;;
 *) echo "stage?";;
 esac
 echo done
