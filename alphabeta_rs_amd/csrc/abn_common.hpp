@@ -143,11 +143,12 @@ struct FitArgs {
   // idle, the chain's outputs stay unwritten), slice_status[1] += chains finished (results written).  The host compares
   // the count with W x C after a time-sliced launch: a lost or never-resumed chain is an error, not stale output.
   unsigned* slice_status;
+#ifdef ABN_MEASUREMENT_KNOBS
   // Wave priority by chain age in the persistent kernel (prio_mode != 0): the wavefront's s_setprio level is the number of
   // thresholds prio_t[] that the evaluations of its OLDEST running chain have passed (mode 1), or 3 minus that (mode 2).
+  // Measured in round 4 (scripts/prio_sweep.sh, profiles/r04_prio_sweep.txt): no gain — kept out of the product build.
   int prio_mode;
   int prio_t[3];
-#ifdef ABN_MEASUREMENT_KNOBS
   int drop_entry;        // fault injection for the tests: FIFO shard 0 never publishes its first entry
 #endif
   double sd_tol;

@@ -296,8 +296,11 @@ __global__ __launch_bounds__(kWave, ABN_REFILL_MIN_WAVES) void abn_fit_refill_ke
     st = done ? ST_DONE : ST_REFLECT;
   };
 
+#ifdef ABN_MEASUREMENT_KNOBS
   int prio_cur = 0;
+#endif
   while (__ballot(st != ST_IDLE) != 0ull) {
+#ifdef ABN_MEASUREMENT_KNOBS
     if (a.prio_mode != 0) {  // wave priority by the age of the wavefront's oldest running chain (scalar code)
       const int e = st != ST_IDLE ? evals : 0;
       int m = 0;
@@ -316,6 +319,7 @@ __global__ __launch_bounds__(kWave, ABN_REFILL_MIN_WAVES) void abn_fit_refill_ke
         else __builtin_amdgcn_s_setprio(3);
       }
     }
+#endif
     const bool in_init = st < ST_REFLECT;                         // Solver::init: start vertex st - ST_INIT0
     const double f = eval(in_init ? vx[0] : xc);
     // ---- decisions of NelderMead::next_iter as predicates (inert for groups in init or idle)

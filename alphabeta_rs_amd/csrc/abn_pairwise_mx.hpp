@@ -83,10 +83,11 @@ __device__ __forceinline__ pmx_u32x4 pmx_load(const uint8_t* codes, size_t off) 
   if constexpr (AL4) {
     return *reinterpret_cast<const pmx_u32x4*>(codes + off);
   } else {
-    const size_t base = off & ~(size_t)3;
-    const unsigned sh = (unsigned)(off & 3);
-    const pmx_u32x4 a = *reinterpret_cast<const pmx_u32x4*>(codes + base);
-    const uint32_t e = *reinterpret_cast<const uint32_t*>(codes + base + 16);
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(codes) + off;   // the caller's buffer itself may be misaligned
+    const uint8_t* base = reinterpret_cast<const uint8_t*>(addr & ~(uintptr_t)3);
+    const unsigned sh = (unsigned)(addr & 3);
+    const pmx_u32x4 a = *reinterpret_cast<const pmx_u32x4*>(base);
+    const uint32_t e = *reinterpret_cast<const uint32_t*>(base + 16);
     pmx_u32x4 r;
     r[0] = __builtin_amdgcn_alignbyte(a[1], a[0], sh);
     r[1] = __builtin_amdgcn_alignbyte(a[2], a[1], sh);
@@ -131,7 +132,6 @@ __global__ __launch_bounds__(kPmxThreads, DIAG ? 2 : 1) void abn_pairwise_mx_ker
   int R, C;
   if constexpr (DIAG) R = C = (int)(a.first + spl);
   else pmx_offdiag(a.first + spl, g, R, C);
-  for (int k = tid; k < kPmxJobElems; k += kPmxThreads) red[k] = 0ull;
 
   // this lane's byte offset in each block's row: sample (clamped: rows past n give sums nobody reads) x L + 16 q
   size_t roff[NF];
@@ -233,6 +233,10 @@ __global__ __launch_bounds__(kPmxThreads, DIAG ? 2 : 1) void abn_pairwise_mx_ker
     auto kfull = [&](long long r) { return Ks + (r * kPmxWaves + wave) * DSTEPS; };
     long long r = 0;
     if (nfull > 0) load_steps(kfull(0), xa, kFull, DSTEPS);
+    // the workgroup's sums start at zero — cleared behind the first loads (they are in flight meanwhile); the barrier keeps
+    // a wavefront that is already at the ragged end (it stages through `red`) from meeting another one's clearing stores
+    for (int k = tid; k < kPmxJobElems; k += kPmxThreads) red[k] = 0ull;
+    __syncthreads();
     while (r < nfull) {
       if (r + 1 < nfull) load_steps(kfull(r + 1), xb, kFull, DSTEPS);
       compute(xa, kFull, DSTEPS);

@@ -80,6 +80,19 @@ def test_gpu_pairwise_many_samples(abn, gpu_ctx, oracle, n, L):
 
 
 @pytest.mark.gpu
+def test_gpu_pairwise_more_jobs_than_one_launch_holds(abn, gpu_ctx, oracle):
+    """8200 samples are 129 groups: 8256 pairs of groups, more than the 8192 jobs whose packed sums one launch keeps — the
+    second family of launches runs in two slabs that reuse the partial rows (stream order).  33.6 M pairs, bit-exact."""
+    n, L = 8200, 40
+    rng = np.random.default_rng(99)
+    status = rng.integers(0, 3, size=(n, L), dtype=np.uint8)
+    pmax = rng.uniform(0.9, 1.0, size=(n, L))
+    diff, both, dval = gpu_ctx.pairwise_divergence(_codes(status, pmax, 0.99))
+    wd, wb, wv = oracle.pairwise_divergence(status, pmax, 0.99)
+    assert np.array_equal(diff, wd) and np.array_equal(both, wb) and np.array_equal(dval, wv, equal_nan=True)
+
+
+@pytest.mark.gpu
 def test_gpu_pairwise_every_state_pair_and_operand_order(abn, gpu_ctx, oracle):
     """Exact-integer check of the matrix-instruction form: every (state_a, state_b) combination of {U, I, M, filtered U/I/M}
     in known counts, on samples in DIFFERENT 16-sample blocks and groups (an asymmetric layout: a transposed tile or a
@@ -128,16 +141,19 @@ def test_gpu_pairwise_device_resident_entry(abn, gpu_ctx, oracle, n, L):
     codes = _codes(status, pmax, 0.99)
     npairs = n * (n - 1) // 2
     bufs = [C.c_void_p() for _ in range(4)]
-    for ptr, size in zip(bufs, (codes.nbytes, 8 * npairs, 8 * npairs, 8 * npairs)):
+    for ptr, size in zip(bufs, (codes.nbytes + 16, 8 * npairs, 8 * npairs, 8 * npairs)):
         assert hip.hipMalloc(C.byref(ptr), size) == 0
-    t, d, b, v = bufs
+    t0, d, b, v = bufs
+    # the codes start at an ODD device address for the even site counts (the caller's buffer need not be aligned: the
+    # kernel then takes its funnel-shift loader although L is a multiple of four)
+    t = C.c_void_p(t0.value + (1 if L % 2 == 0 else 0))
     assert hip.hipMemcpy(t, codes.ctypes.data, codes.nbytes, 1) == 0
     ms = gpu_ctx.pairwise_divergence_dev(t.value, n, L, d.value, b.value, v.value)
     assert ms > 0
     dd, db, dv = np.zeros(npairs, np.uint64), np.zeros(npairs, np.uint64), np.zeros(npairs)
     for host, dev in ((dd, d), (db, b), (dv, v)):
         assert hip.hipMemcpy(host.ctypes.data, dev, 8 * npairs, 2) == 0
-    for ptr in bufs:
+    for ptr in (t0, d, b, v):
         hip.hipFree(ptr)
     hd, hb, hv = gpu_ctx.pairwise_divergence(codes)
     assert np.array_equal(dd, hd) and np.array_equal(db, hb) and np.array_equal(dv, hv, equal_nan=True)
