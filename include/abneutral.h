@@ -190,7 +190,9 @@ int abn_analyze(const double* raw, int64_t n_boot, double* out32);
  * Outputs per unordered pair i < j at index p = i*n - i*(i+1)/2 + (j - i - 1) (the nested-loop order of
  * :214-215):  diff[p] = sum of |status_i - status_j| over sites valid in both (:253),  both[p] = number of
  * such sites (:254),  dvalue[p] = diff / (2 * both) in f64 (:257; NaN for both == 0 like the reference's
- * 0/0).  Integer sums are exact, so the result does not depend on the device's summation order. */
+ * 0/0).  Integer sums are exact, so the result does not depend on the device's summation order.
+ * Any number of samples up to 65535 (the reference has no limit; the sample axis is tiled in groups of 64), any
+ * number of sites, codes at any byte alignment.  Bytes other than 0, 1, 2 (| 0x80) are not valid codes. */
 int abn_pairwise_divergence(abn_ctx* ctx, const uint8_t* codes, int32_t n_samples, int64_t n_sites,
                             uint64_t* diff, uint64_t* both, double* dvalue);
 /* The same on DEVICE-resident buffers (no PCIe in the call): dev_codes u8[n x n_sites]; dev_diff / dev_both
