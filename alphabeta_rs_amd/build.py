@@ -13,7 +13,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libabneutral_hip.so"
-SOURCES = [CSRC / "abn_api.hip", CSRC / "abn_multi.hip"]
+SOURCES = [CSRC / "abn_api.hip", CSRC / "abn_pairwise.hip", CSRC / "abn_multi.hip"]
 DEPS = [*sorted(CSRC.glob("*.hpp")), CSRC / "abn_philox.h", PKG.parent / "include" / "abneutral.h"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",

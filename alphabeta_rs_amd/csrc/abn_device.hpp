@@ -1,8 +1,8 @@
-// All device code of libabneutral_hip.so (one translation unit per .hip file includes this).
+// The device code of the fit path (abn_api.hip includes this; the pairwise scan of abn_pairwise.hip has its own header,
+// abn_pairwise_mx.hpp).
 #pragma once
 #include "abn_common.hpp"
 #include "abn_fit_kernel.hpp"
 #include "abn_fit_refill.hpp"
 #include "abn_fit_spec.hpp"
 #include "abn_aux_kernels.hpp"
-#include "abn_pairwise_mx.hpp"

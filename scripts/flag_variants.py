@@ -22,7 +22,7 @@ for i, flags in enumerate(args or [""]):
     lib = OUT / f"libabn_flags_{i}.so"
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
            "-shared", "-ldl", *flags.split(), "-o", str(lib), str(ROOT / "alphabeta_rs_amd/csrc/abn_api.hip"),
-           str(ROOT / "alphabeta_rs_amd/csrc/abn_multi.hip")]
+           str(ROOT / "alphabeta_rs_amd/csrc/abn_pairwise.hip"), str(ROOT / "alphabeta_rs_amd/csrc/abn_multi.hip")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         print(f"[{flags}] build failed: {r.stderr[-400:]}")

@@ -10,7 +10,7 @@ lib = ROOT / "gpurun_out" / "libabneutral_hip_stamps.so"
 lib.parent.mkdir(exist_ok=True)
 subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-ldl",
                 "-DABN_STAMPS", "-DABN_MEASUREMENT_KNOBS", "-o", str(lib), str(ROOT / "alphabeta_rs_amd/csrc/abn_api.hip"),
-                str(ROOT / "alphabeta_rs_amd/csrc/abn_multi.hip")], check=True)
+                str(ROOT / "alphabeta_rs_amd/csrc/abn_pairwise.hip"), str(ROOT / "alphabeta_rs_amd/csrc/abn_multi.hip")], check=True)
 import alphabeta_rs_amd as A
 A.LIB_PATH = lib
 A._lib = None
