@@ -323,7 +323,21 @@ static int launch_fit_spec(abn_ctx* c, FitArgs a, hipStream_t st) {
   const size_t lds = (3 * (size_t)a.chain_stride + kSpecCommDoubles) * sizeof(double);
   dim3 grid((unsigned)chains), block(4 * kWave);
   a.tree = a.strict ? 1 : kTreeCanon;  // spec_applicable admitted it
-  if (a.strict) {
+  // more chains than three workgroups per CU hold, at most four per CU (spec_max_chains), one or two rows per lane: the
+  // build of the kernel for four workgroups per CU keeps them all resident (C2's 1000 bootstraps: 1.65 -> 1.60 ms; the reference default -i 1000 on the C3 pedigree: 519 k -> 565 k fits/s, profiles/r04_spec_dense_ab.txt)
+  bool dense = rmax <= 2 && chains > 3LL * c->cus && lds * 4 <= c->lds_per_cu;
+#ifdef ABN_MEASUREMENT_KNOBS
+  if (const char* e = getenv("ABN_SPEC_DENSE")) dense = dense && atoi(e) != 0;
+#endif
+  if (dense) {
+    if (a.strict) {
+      if (rmax == 1) hipLaunchKernelGGL((abn_fit_spec_kernel<1, true, true>), grid, block, lds, st, a);
+      else hipLaunchKernelGGL((abn_fit_spec_kernel<2, true, true>), grid, block, lds, st, a);
+    } else {
+      if (rmax == 1) hipLaunchKernelGGL((abn_fit_spec_kernel<1, false, true>), grid, block, lds, st, a);
+      else hipLaunchKernelGGL((abn_fit_spec_kernel<2, false, true>), grid, block, lds, st, a);
+    }
+  } else if (a.strict) {
     switch (rmax) {
       case 1: hipLaunchKernelGGL((abn_fit_spec_kernel<1, true>), grid, block, lds, st, a); break;
       case 2: hipLaunchKernelGGL((abn_fit_spec_kernel<2, true>), grid, block, lds, st, a); break;

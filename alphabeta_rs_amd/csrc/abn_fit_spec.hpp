@@ -39,8 +39,12 @@ constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16 + 2 * kSpecPreDoub
 
 // STRICT (abn_options.strict_order): the evaluation wavefronts sum the residuals serially in row order (terms to LDS, N
 // more doubles per wavefront, then serial_sum_lds) — the reference's order, the oracle's lanes = 1.
-template <int RMAX, bool STRICT = false>
-__global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 3 : 2) void abn_fit_spec_kernel(const FitArgs a) {
+// DENSE (pedigrees of up to two rows per lane): compiled for FOUR workgroups per CU (128 registers, a few spilled) instead
+// of three — for launches of more chains than three per CU hold but no more than four (the reference's default 1000 starts /
+// 1000 bootstraps on 256 CUs): every chain resident at once instead of a second round of late starters.  Same code, same bits.
+template <int RMAX, bool STRICT = false, bool DENSE = false>
+__global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void abn_fit_spec_kernel(const FitArgs a) {
+  static_assert(!DENSE || RMAX <= 2, "four workgroups per CU: one or two rows per lane only");
   constexpr int G = kWave;
   extern __shared__ __align__(16) double lds[];
   const int wv = threadIdx.x >> 6;      // 0: reflection, 1: expansion, 2: contraction, 3: keeper
