@@ -45,7 +45,7 @@ EXPORTED_SYMBOLS = [
     "abn_status_string", "abn_version", "abn_cost_batch", "abn_fit_batch", "abn_gen_start_simplices",
     "abn_gen_boot_simplices", "abn_gen_boot_indices", "abn_ab_neutral_run", "abn_boot_model_run",
     "abn_analyze", "abn_select_best", "abn_bootstrap_rows", "abn_pairwise_divergence", "abn_plan_create", "abn_plan_destroy", "abn_plan_set_windows", "abn_plan_run",
-    "abn_plan_run_phase", "abn_plan_sync", "abn_plan_kernel_ms", "abn_plan_raw_device_ptr",
+    "abn_plan_run_phase", "abn_plan_sync", "abn_plan_tail_handed", "abn_plan_kernel_ms", "abn_plan_raw_device_ptr",
     "abn_plan_bind_raw", "abn_plan_download", "abn_plan_counters", "abn_plan_device_bytes",
     "abn_plan_set_window_ids", "abn_plan_failed_windows",
     "abn_multi_create", "abn_multi_destroy", "abn_multi_last_error", "abn_multi_set_windows", "abn_multi_run",
@@ -129,6 +129,7 @@ def load_library(build_if_missing: bool = False) -> C.CDLL:
     L.abn_plan_run.argtypes = [vp]
     L.abn_plan_run_phase.argtypes = [vp, C.c_int32]
     L.abn_plan_sync.argtypes = [vp]
+    L.abn_plan_tail_handed.argtypes = [vp, C.POINTER(C.c_int64)]
     L.abn_plan_kernel_ms.argtypes = [vp, dp]
     L.abn_plan_raw_device_ptr.argtypes = [vp, C.POINTER(vp)]
     L.abn_plan_bind_raw.argtypes = [vp, vp]
@@ -425,6 +426,12 @@ class Plan:
 
     def sync(self):
         self.ctx._check(self._L.abn_plan_sync(self._h))
+
+    def tail_handed(self):
+        """chains the last persistent launch of (phase A, phase B) handed to the speculative kernel for its tail"""
+        out = (C.c_int64 * 2)()
+        self.ctx._check(self._L.abn_plan_tail_handed(self._h, out))
+        return int(out[0]), int(out[1])
 
     def kernel_ms(self):
         ms = np.zeros(3)

@@ -135,6 +135,8 @@ static int pick_lanes(int n, int requested, int chain_stride) {
 }
 static bool fit_streams(int n, int chain_stride, int lanes, int strict = 0);
 static bool tree_on_wave_ok(int n_rows, int chain_stride, int tree, int strict);
+static bool spec_applicable(const FitArgs& a);
+static int launch_fit_spec(abn_ctx* c, FitArgs a, hipStream_t st);
 // The residual reduction tree (FitArgs::tree; abn_fit_info.lanes).  Auto (lanes_per_chain == 0) and the pedigree
 // LDS-resident: the canonical 64-accumulator tree, which every kernel — packed, one wavefront per chain, four
 // wavefronts per chain — runs at its native cost.  Streamed pedigrees and explicit lane counts: one accumulator per
@@ -205,6 +207,7 @@ static hipError_t launch_fit_g(const FitArgs& a, int rmax, dim3 grid, size_t lds
 // kind (nullable): the ABN_KERNEL_* code of what was launched (PERSISTENT: a.slice_status then counts its fits)
 static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, int* kind = nullptr) {
   if (kind) *kind = ABN_KERNEL_NONE;
+  const FitArgs a0 = a;  // as the caller set it (topology's scratch stride): the tail's resume launch starts from it
   const long long chains = (long long)a.W * a.C;
   if (chains <= 0) return ABN_OK;
   const int ng = kWave / lanes;
@@ -255,7 +258,20 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, int* kin
     if (const char* e = getenv("ABN_DROP_FIFO_ENTRY")) a.drop_entry = atoi(e);
   }
 #endif
-  if (refill && a.slice_status) HIPCHK(c, hipMemsetAsync(a.slice_status, 0, 2 * sizeof(unsigned), st));
+  // Tail hand-over (FitArgs::tail_cap): the last chains of a time-sliced launch — as many as abn_fit_spec_kernel keeps resident
+  // — finish on four wavefronts each instead of one by one on an emptying GPU at the packed kernel's step time
+  // (metaprofile shape, phase A: 12 of 17 ms were such a tail).  Needs the speculative kernel to apply to the pedigree.
+  a.tail_cap = 0;
+  if (refill && a.quantum > 0 && a.slice_status && a.susp_list && a.tree == kTreeCanon) {
+    FitArgs probe = a0;
+    probe.tree = kTreeCanon;
+    if (spec_applicable(probe)) a.tail_cap = (int)((pick_rmax(a.N, kWave) <= 2 ? 4LL : 2LL) * c->cus);
+#ifdef ABN_MEASUREMENT_KNOBS
+    if (const char* e = getenv("ABN_TAIL_CAP")) a.tail_cap = std::min(a.tail_cap, std::max(0, atoi(e)));
+#endif
+    a.susp_count = reinterpret_cast<int*>(a.slice_status + 3);
+  }
+  if (refill && a.slice_status) HIPCHK(c, hipMemsetAsync(a.slice_status, 0, 4 * sizeof(unsigned), st));
   if (kind)
     *kind = refill ? ABN_KERNEL_PERSISTENT
             : rmax <= 0 ? ABN_KERNEL_STREAM
@@ -273,6 +289,19 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, int* kin
     default: e = launch_fit_g<64>(a, rmax, grid, lds, st, refill); break;
   }
   HIPCHK(c, e);
+  if (a.tail_cap > 0) {  // the parked tail (possibly empty: workgroups beyond *susp_count leave at once)
+    FitArgs r = a0;
+    r.tree = kTreeCanon;
+    r.queue = nullptr;
+    r.quantum = 0;
+    r.spec_resume = 1;
+    r.tail_cap = a.tail_cap;
+    r.state = a.state;
+    r.susp_list = a.susp_list;
+    r.susp_count = a.susp_count;
+    r.slice_status = a.slice_status;
+    if (int rc = launch_fit_spec(c, r, st)) return rc;
+  }
   return ABN_OK;
 }
 
@@ -316,7 +345,8 @@ static bool spec_applicable(const FitArgs& a) {
 }
 
 static int launch_fit_spec(abn_ctx* c, FitArgs a, hipStream_t st) {
-  const long long chains = (long long)a.W * a.C;
+  // spec_resume: one workgroup per slot of the tail list (at most tail_cap chains were handed over)
+  const long long chains = a.spec_resume ? (long long)a.tail_cap : (long long)a.W * a.C;
   if (chains <= 0) return ABN_OK;
   const int rmax = pick_rmax(a.N, kWave);
   a.chain_stride += ((a.N + 1) & ~1) * (a.strict ? 2 : 1);
@@ -798,8 +828,10 @@ struct abn_plan {
   bool twopass_a = false;
   DevBuf<int> slice_buf;      // time slicing: head, tail, then the FIFO of parked chains
   unsigned slice_cap = 0;
-  DevBuf<unsigned> slice_status;   // per phase: error word, fits finished by the persistent kernel (FitArgs::slice_status)
+  DevBuf<unsigned> slice_status;   // per phase four words: error word, fits finished by the persistent launch (and its tail's
+                                   // resume launch), chains handed to the tail, the tail list's fill count (FitArgs::slice_status)
   long long persist_expected[2] = {0, 0};  // chains the last persistent launch of phase A / B had to finish (0: none)
+  long long tail_handed[2] = {0, 0};       // ... of which its tail handed to the speculative kernel (read at the last sync)
   int32_t last_kernels[4] = {0, 0, 0, 0};  // abn_plan_last_kernels
   bool stream_b = false;
   double* raw = nullptr;  // raw_own.p or caller-bound
@@ -900,7 +932,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
   PALLOC(infoB, W * B);
   PALLOC(raw_own, W * B * 7);
   PALLOC(skipped, 4);
-  PALLOC(slice_status, 4);
+  PALLOC(slice_status, 8);
   // Phase A with many chains when the repetitions of stuck fits must be executed (no_fixed_point_skip): 7 % of
   // random starts run into argmin's fixed point and repeat it up to iteration 10000; dispatched late in one launch
   // such a chain runs alone for tens of milliseconds.  Two passes: every chain for at most kPhaseACap iterations,
@@ -919,6 +951,7 @@ extern "C" int abn_plan_create(abn_ctx* c, const abn_options* opts, const double
       if (p->nm_state.n < chains * 32) PALLOC(nm_state, chains * 32);
       p->slice_cap = (unsigned)(chains * 16 / kParkShards + 4096);   // per shard; a full shard just stops parking
       PALLOC(slice_buf, (size_t)kParkShards * ((size_t)kParkHeaderInts + (size_t)p->slice_cap));
+      if (p->susp_list.n < chains + 1) PALLOC(susp_list, chains + 1);  // the tail list of the hand-over to the speculative kernel
     }
   }
   p->stream_b = n_boot > 0 && fit_streams(n_rows, p->topo.chain_stride, p->lanes, p->opt.strict_order) && p->opt.stream_mode == 0;
@@ -1058,6 +1091,7 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
     a.park_ht = reinterpret_cast<unsigned*>(p->slice_buf.p);
     a.parked = p->slice_buf.p + kParkShards * kParkHeaderInts;
     a.state = p->nm_state.p;
+    a.susp_list = p->susp_list.p;   // tail hand-over (launch_fit decides whether it applies)
   }
   const bool whole = w0 == 0 && wn == p->W;   // window groups on side streams share the plan's status words: unchecked
   if (whole) a.slice_status = p->slice_status.p;
@@ -1165,9 +1199,10 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
     a.park_ht = reinterpret_cast<unsigned*>(p->slice_buf.p);
     a.parked = p->slice_buf.p + kParkShards * kParkHeaderInts;
     a.state = p->nm_state.p;
+    a.susp_list = p->susp_list.p;   // tail hand-over (launch_fit decides whether it applies)
   }
   const bool whole = w0 == 0 && wn == p->W;
-  if (whole) a.slice_status = p->slice_status.p + 2;
+  if (whole) a.slice_status = p->slice_status.p + 4;
   int kind = ABN_KERNEL_SPECULATIVE;
   if (timed) HIPCHK(c, hipEventRecord(p->ev[4], st));
   if (p->stream_b) {  // gather the bootstrap observations once per fit, then stream them
@@ -1302,16 +1337,17 @@ extern "C" int abn_plan_run(abn_plan* p) {
 static int verify_persistent(abn_plan* p) {
   abn_ctx* c = p->ctx;
   HIPCHK(c, hipSetDevice(c->device));
-  unsigned sl[4] = {0, 0, 0, 0};
+  unsigned sl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool check = p->persist_expected[0] > 0 || p->persist_expected[1] > 0;
   if (check) HIPCHK(c, hipMemcpyAsync(sl, p->slice_status.p, sizeof sl, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int ph = 0; ph < 2 && check; ++ph) {
     if (p->persist_expected[ph] <= 0) continue;
-    if (sl[2 * ph] != 0 || (long long)sl[2 * ph + 1] != p->persist_expected[ph])
+    p->tail_handed[ph] = (long long)sl[4 * ph + 2];
+    if (sl[4 * ph] != 0 || (long long)sl[4 * ph + 1] != p->persist_expected[ph])
       return set_err(c, ABN_ERR_HIP, std::string("persistent fit launch of phase ") + (ph ? "B" : "A") + " finished " +
-                                         std::to_string(sl[2 * ph + 1]) + " of " + std::to_string(p->persist_expected[ph]) +
-                                         " chains (error word " + std::to_string(sl[2 * ph]) + "): results are incomplete");
+                                         std::to_string(sl[4 * ph + 1]) + " of " + std::to_string(p->persist_expected[ph]) +
+                                         " chains (error word " + std::to_string(sl[4 * ph]) + "): results are incomplete");
   }
   return ABN_OK;
 }
@@ -1319,6 +1355,14 @@ static int verify_persistent(abn_plan* p) {
 extern "C" int abn_plan_sync(abn_plan* p) {
   if (!p) return ABN_ERR_INVALID_ARG;
   return verify_persistent(p);
+}
+
+extern "C" int abn_plan_tail_handed(abn_plan* p, int64_t* out2) {
+  if (!p || !out2) return ABN_ERR_INVALID_ARG;
+  const int rc = verify_persistent(p);  // synchronises the stream and reads the counts of the last persistent launches
+  out2[0] = p->persist_expected[0] > 0 ? p->tail_handed[0] : 0;
+  out2[1] = p->persist_expected[1] > 0 ? p->tail_handed[1] : 0;
+  return rc;
 }
 
 extern "C" int abn_plan_kernel_ms(abn_plan* p, double* ms3) {

@@ -143,6 +143,14 @@ struct FitArgs {
   // idle, the chain's outputs stay unwritten), slice_status[1] += chains finished (results written).  The host compares
   // the count with W x C after a time-sliced launch: a lost or never-resumed chain is an error, not stale output.
   unsigned* slice_status;
+  // Tail hand-over of a time-sliced persistent launch (tail_cap > 0): once no chain waits any more (queue and this workgroup's
+  // FIFO empty) and at most tail_cap chains of the launch are unfinished, the running chains park at their next iteration
+  // boundary — state as for time slicing, index appended to susp_list — and the launch ends; abn_fit_spec_kernel (spec_resume
+  // != 0: workgroup b takes chain susp_list[b], b < *susp_count, up from `state`) runs them to the end with four wavefronts
+  // per chain: the long chains that would otherwise finish one by one on an emptying GPU at the packed kernel's step time.
+  // Same arithmetic, same bits; slice_status[2] counts the chains handed over.
+  int tail_cap;
+  int spec_resume;
 #ifdef ABN_MEASUREMENT_KNOBS
   // Wave priority by chain age in the persistent kernel (prio_mode != 0): the wavefront's s_setprio level is the number of
   // thresholds prio_t[] that the evaluations of its OLDEST running chain have passed (mode 1), or 3 minus that (mode 2).

@@ -78,6 +78,10 @@ __global__ __launch_bounds__(kWave, ABN_REFILL_MIN_WAVES) void abn_fit_refill_ke
   int fin_status = 2;
   int q_start = 0;           // time slicing: evals of this chain when its current quantum began
   bool fresh_done = false;   // this group has seen the queue of unstarted chains empty
+  bool wave_fd = false;      // ... some group of this wavefront has (wavefront-uniform)
+  bool tail_mode = false;    // tail hand-over: every running chain of this wavefront parks at its next iteration boundary
+  bool tail_park = false;    // this chain's park goes to the tail list, not to the FIFO
+  unsigned wstep = 0;
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     vx[k] = 0.0;
@@ -284,6 +288,11 @@ __global__ __launch_bounds__(kWave, ABN_REFILL_MIN_WAVES) void abn_fit_refill_ke
       suspend = __builtin_amdgcn_ds_bpermute(4 * (g * G), verdict) != 0;  // the group leader's reading
       q_start = evals;
     }
+    tail_park = false;
+    if (tail_mode && status < 0 && !suspend) {   // tail hand-over: to the list of abn_fit_spec_kernel's resume launch
+      suspend = true;
+      tail_park = true;
+    }
     const bool done = status >= 0 || suspend;
     fin_status = (status >= 0) ? (have_best ? status : 2) : (suspend ? kFitSuspended : fin_status);
     double acc = vx[0];
@@ -320,6 +329,18 @@ __global__ __launch_bounds__(kWave, ABN_REFILL_MIN_WAVES) void abn_fit_refill_ke
       }
     }
 #endif
+    // tail hand-over: once a group of this wavefront has seen the queue empty, lane 0 looks every 64 steps whether nobody
+    // waits any more (queue, this workgroup's FIFO) and at most tail_cap chains of the launch are unfinished
+    if (a.tail_cap > 0 && wave_fd && !tail_mode && (++wstep & 63u) == 0u) {
+      int t = 0;
+      if (lane == 0) {
+        const unsigned fq = __hip_atomic_load(a.queue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int av = __hip_atomic_load(reinterpret_cast<int*>(pht) + kParkAvail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned fin = __hip_atomic_load(a.slice_status + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = (gridDim.x * NG + fq >= total && av <= 0 && total - fin <= (unsigned)a.tail_cap) ? 1 : 0;
+      }
+      tail_mode = __builtin_amdgcn_readfirstlane(t) != 0;
+    }
     const bool in_init = st < ST_REFLECT;                         // Solver::init: start vertex st - ST_INIT0
     const double f = eval(in_init ? vx[0] : xc);
     // ---- decisions of NelderMead::next_iter as predicates (inert for groups in init or idle)
@@ -445,7 +466,11 @@ __global__ __launch_bounds__(kWave, ABN_REFILL_MIN_WAVES) void abn_fit_refill_ke
         // state stores and the entry store.  All of this wavefront's entries are out before any of its groups looks for
         // one (no group can wait for an entry of its own wavefront).
         if (__ballot(parking) != 0ull) asm volatile("s_waitcnt vmcnt(0) ; abn: parked state written through" ::: "memory");
-        if (parking && gl == 0) {
+        if (parking && tail_park && gl == 0) {   // to the resume launch of abn_fit_spec_kernel (a kernel boundary away)
+          a.susp_list[atomicAdd(a.susp_count, 1)] = (int)chain;
+          atomicAdd(a.slice_status + 2, 1u);
+        }
+        if (parking && !tail_park && gl == 0) {
           const unsigned pos = atomicAdd(pht + kParkTail, 1u);
 #ifdef ABN_MEASUREMENT_KNOBS
           if (!(a.drop_entry != 0 && pos == 0 && (blockIdx.x & (kParkShards - 1)) == 0))
@@ -491,6 +516,7 @@ __global__ __launch_bounds__(kWave, ABN_REFILL_MIN_WAVES) void abn_fit_refill_ke
       nxt = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (g * G), (int)nxt);  // the group leader's draw
       take_parked = __builtin_amdgcn_ds_bpermute(4 * (g * G), (int)take_parked) != 0;
       fresh_done = __builtin_amdgcn_ds_bpermute(4 * (g * G), (int)fresh_done) != 0;
+      wave_fd = wave_fd || (__ballot(fresh_done) != 0ull);
       if (fin) {
         st = ST_IDLE;
         if (nxt < total) {

@@ -51,7 +51,11 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
   const int gl = threadIdx.x & 63;
   const int dim = gl & 3;
   const bool keeper = wv == 3;
-  const long long chain = blockIdx.x;   // grid = W*C exactly
+  long long chain = blockIdx.x;         // grid = W*C exactly ...
+  if (a.spec_resume) {                  // ... or the tail of a persistent launch: slot b takes a parked chain up again
+    if ((int)blockIdx.x >= *a.susp_count) return;   // (uniform in the workgroup, before any barrier)
+    chain = a.susp_list[blockIdx.x];
+  }
   const int w = (int)(chain / a.C);
   const int N = a.N, K = a.K, TP = a.TP;
 
@@ -95,7 +99,11 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
   } else {
     // start simplex (starts: given; bootstraps: [params, vary() x4], src/boot_model.rs:69-75), handed to the
     // evaluation wavefronts through the (still unused) candidate table
-    if (a.smode == 0) {
+    if (a.spec_resume) {   // the sorted simplex as abn_fit_refill_kernel parked it at an iteration boundary
+      const double* sp = a.state + (size_t)chain * 32;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) vx[k] = sp[4 * k + dim];
+    } else if (a.smode == 0) {
       const double* s0 = a.simplex0 + (size_t)chain * 20;
 #pragma unroll
       for (int k = 0; k < 5; ++k) vx[k] = s0[4 * k + dim];
@@ -347,21 +355,38 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
     return done;
   };
 
-  // ---- Solver::init: the five start costs in input order (3 + 2), stable sort, first termination check
-  cand = keeper ? 0.0 : tab[4 * wv + dim];
-  exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
-  c[0] = f0;
-  c[1] = f1;
-  c[2] = f2;
-  cand = keeper ? 0.0 : tab[4 * (wv == 0 ? 3 : 4) + dim];
-  exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
-  c[3] = f0;
-  c[4] = f1;
-  evals = 5;
-  if (keeper) {
-    sort5(c, vx);
-    status = ctl_begin(false, improved);
-    if (improved) bx = vx[0];
+  if (a.spec_resume) {
+    // a chain parked by the persistent kernel at an iteration boundary (IterState::update and the termination test of that
+    // iteration are behind it: status < 0): costs, best vertex and counters as stored, then straight to the candidates
+    if (keeper) {
+      const double* sp = a.state + (size_t)chain * 32;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) c[k] = sp[20 + k];
+      bx = sp[25 + dim];
+      best_cost = sp[29];
+      const long long ie = __double_as_longlong(sp[30]);
+      iter = (int)(ie & 0xffffffffll);
+      evals = (int)(ie >> 32);
+      have_best = __double_as_longlong(sp[31]) != 0;
+      status = -1;
+    }
+  } else {
+    // ---- Solver::init: the five start costs in input order (3 + 2), stable sort, first termination check
+    cand = keeper ? 0.0 : tab[4 * wv + dim];
+    exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
+    c[0] = f0;
+    c[1] = f1;
+    c[2] = f2;
+    cand = keeper ? 0.0 : tab[4 * (wv == 0 ? 3 : 4) + dim];
+    exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
+    c[3] = f0;
+    c[4] = f1;
+    evals = 5;
+    if (keeper) {
+      sort5(c, vx);
+      status = ctl_begin(false, improved);
+      if (improved) bx = vx[0];
+    }
   }
   bool done = publish();
 
@@ -535,6 +560,7 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
   if (keeper) {
     if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
     if (gl == 0) {
+      if (a.spec_resume && a.slice_status) atomicAdd(a.slice_status + 1, 1u);  // the persistent launch's count of finished fits
       FitInfoDev fo;
       fo.best_cost = best_cost;
       fo.iters = iter;

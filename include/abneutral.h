@@ -224,6 +224,10 @@ int abn_plan_set_windows(abn_plan* plan, const double* d_obs, const double* p0uu
 int abn_plan_run(abn_plan* plan);
 int abn_plan_run_phase(abn_plan* plan, int32_t phase /* 0 = A+select, 1 = B */);
 int abn_plan_sync(abn_plan* plan);
+/* Diagnostics: out2 = chains the last persistent (queue + time-sliced) launch of phase A / phase B handed to its tail — the
+ * last chains of such a launch finish on abn_fit_spec_kernel (four wavefronts per chain) instead of one by one on an
+ * emptying GPU; 0 when the phase did not run persistent.  Same bits either way.  Synchronises like abn_plan_sync. */
+int abn_plan_tail_handed(abn_plan* plan, int64_t* out2);
 /* HIP-event time of the most recent launch of each kernel, in milliseconds (fit A, select, fit B) */
 int abn_plan_kernel_ms(abn_plan* plan, double* ms3);
 /* device pointer of raw[W x B x 7] (for an RCCL gather by the caller) and optional rebinding to a
