@@ -4,8 +4,8 @@ under profiles/.  Usage (scripts/profile_round.sh does all of it on the GPU box)
   python profiles/summarize_rocprof.py gpurun_out/prof_c3 r04_c3 c3 <repo root>
 Writes  <tag>_kernel_stats.csv, <tag>_rocprof_summary.json  and  <round>_pmc_<workload>.json: per PHASE of a step
 (fit_starts = the fit launches before the selection kernel, fit_boot = those after it — two phases may run the same
-kernel on the same grid, so the split is by dispatch order, not by name) the averages per launch of every counter
-collected, the HBM bytes derived from them and the content hash of the kernel sources they belong to (bench.py quotes
+kernel on the same grid, so the split is by dispatch order, not by name; the launches of a phase are added up) the averages
+of every counter collected, the HBM bytes derived from them and the content hash of the kernel sources they belong to (bench.py quotes
 them only for that very build).
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads
@@ -32,18 +32,22 @@ def newest(pattern):   # gpurun merges every run's files into the same directori
 
 
 def phases_of(rows, name_key, order_key):
-    """[(phase, row)] for the fit launches of `rows` in dispatch order: fit_starts until a selection kernel has been seen,
-    fit_boot after it (abn_make_dstar_kernel belongs to phase B: it materialises the bootstrap observations); the fit
-    launch of phase B ends the step."""
-    state, out_rows = "fit_starts", []
+    """[(step, phase, row)] for the fit launches of `rows` in dispatch order.  A step of a plan: a buffer fill (the skip
+    counters are cleared), the fit launches of phase A, the two selection kernels, fills, (abn_make_dstar_kernel,) the fit
+    launches of phase B — a persistent launch may be followed by its tail's resume launch on abn_fit_spec_kernel, so a phase
+    can hold two fit launches: phase B lasts from the selection until the first buffer fill behind one of its fit launches."""
+    state, step, out_rows = "fit_starts", 0, []
     for r in sorted(rows, key=lambda r: int(r[order_key])):
         n = r[name_key]
         if "abn_select" in n:
-            state = "fit_boot"
+            state = "fit_boot_pending"
+        elif "fillBuffer" in n:
+            if state == "fit_boot":
+                state, step = "fit_starts", step + 1
         elif "abn_fit_" in n or "abn_make_dstar" in n:
-            out_rows.append((state, r))
-            if state == "fit_boot" and "abn_fit_" in n:
-                state = "fit_starts"
+            if state == "fit_boot_pending" and "abn_fit_" in n:
+                state = "fit_boot"
+            out_rows.append((step, "fit_boot" if state.startswith("fit_boot") else "fit_starts", r))
     return out_rows
 
 
@@ -63,34 +67,37 @@ if trace:
         dur[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     for k, v in dur.items():
         summary["kernels"][k] = {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
-    ph = collections.defaultdict(list)
-    for p, r in phases_of(rows, "Kernel_Name", "Dispatch_Id"):
+    ph = collections.defaultdict(lambda: collections.defaultdict(float))
+    for st, p, r in phases_of(rows, "Kernel_Name", "Dispatch_Id"):
         if "abn_fit_" in r["Kernel_Name"]:
-            ph[p].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    summary["fit_launch_avg_us_by_phase"] = {p: sum(v) / len(v) for p, v in ph.items()}
+            ph[p][st] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    summary["fit_launches_us_per_step_by_phase"] = {p: sum(v.values()) / len(v) for p, v in ph.items()}
 
 # ---- counters, per phase
-pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-kern = {}
+pmc = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))  # phase, counter, step
+kern = collections.defaultdict(list)
 for d in sorted(glob.glob(str(src / "pmc_*"))):
     f = newest(d + "/*/*_counter_collection.csv")
     if not f:
         continue
     rows = list(csv.DictReader(open(f)))
-    # one row per (dispatch, counter): split the dispatches into phases once per file
+    # one row per (dispatch, counter): split the dispatches into steps and phases once per file
     seen, disp = set(), []
     for r in rows:
         if r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"])
             disp.append(r)
-    phase_of = {r["Dispatch_Id"]: p for p, r in phases_of(disp, "Kernel_Name", "Dispatch_Id")
-                if "abn_fit_" in r["Kernel_Name"]}
+    where = {r["Dispatch_Id"]: (st, p) for st, p, r in phases_of(disp, "Kernel_Name", "Dispatch_Id")
+             if "abn_fit_" in r["Kernel_Name"]}
     for r in rows:
-        p = phase_of.get(r["Dispatch_Id"])
-        if p:
-            pmc[p][r["Counter_Name"]].append(float(r["Counter_Value"]))
-            kern[p] = f"{r['Kernel_Name']} grid={r['Grid_Size']}"
-summary["pmc_avg_per_launch"] = {p: {c: sum(x) / len(x) for c, x in v.items()} for p, v in pmc.items()}
+        sp = where.get(r["Dispatch_Id"])
+        if sp:
+            st, p = sp
+            pmc[p][r["Counter_Name"]][st] += float(r["Counter_Value"])   # a phase's launches of one step add up
+            k = f"{r['Kernel_Name']} grid={r['Grid_Size']}"
+            if k not in kern[p]:
+                kern[p].append(k)
+summary["pmc_avg_per_phase_of_a_step"] = {p: {c: sum(x.values()) / len(x) for c, x in v.items()} for p, v in pmc.items()}
 
 h = hashlib.sha1()  # the same content hash bench.py computes: the figures belong to these kernel sources
 for f in sorted((root / "alphabeta_rs_amd" / "csrc").glob("*")):
@@ -100,8 +107,8 @@ for f in sorted((root / "alphabeta_rs_amd" / "csrc").glob("*")):
         h.update(f.name.encode())
         h.update(f.read_bytes())
 phases = {}
-for p, c in summary["pmc_avg_per_launch"].items():
-    e = {"kernel": kern[p], **{k: v for k, v in c.items()}}
+for p, c in summary["pmc_avg_per_phase_of_a_step"].items():
+    e = {"kernel": " + ".join(kern[p]), **{k: v for k, v in c.items()}}
     if "FETCH_SIZE" in c:
         e["hbm_bytes_per_launch"] = (2 * c["FETCH_SIZE"] + c.get("WRITE_SIZE", 0.0)) * 1024
         e["hbm_bytes_has_write_pass"] = "WRITE_SIZE" in c
@@ -109,7 +116,9 @@ for p, c in summary["pmc_avg_per_launch"].items():
 if phases:
     (out / f"{tag.split('_')[0]}_pmc_{workload}.json").write_text(json.dumps(
         {"workload": workload, "phases": phases, "source_sha1": h.hexdigest(),
-         "units": "averages per launch; FETCH_SIZE / WRITE_SIZE in KiB, hbm_bytes = (2 FETCH + WRITE) x 1024 (gfx950 "
+         "units": "averages per PHASE of a step (its fit launches added up: a persistent launch and its tail's resume launch "
+                  "count together; the key hbm_bytes_per_launch is kept for the phase total); FETCH_SIZE / WRITE_SIZE in "
+                  "KiB, hbm_bytes = (2 FETCH + WRITE) x 1024 (gfx950 "
                   "correction); SQ_ACTIVE_* / SQ_WAIT_* / SQ_WAVE_CYCLES / SQ_BUSY_CYCLES in quad-cycles summed over "
                   "wavefronts (resp. SQs); SQ_INSTS_* in wavefront instructions",
          "collected": datetime.date.today().isoformat()}, indent=1))
