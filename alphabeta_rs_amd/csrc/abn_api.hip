@@ -359,7 +359,12 @@ static int launch_fit_spec(abn_ctx* c, FitArgs a, hipStream_t st) {
 #ifdef ABN_MEASUREMENT_KNOBS
   if (const char* e = getenv("ABN_SPEC_DENSE")) dense = dense && atoi(e) != 0;
 #endif
-  if (dense) {
+  if (a.spec_resume) {  // the tail of a persistent launch (never strict): dense where it exists
+    if (rmax == 1) hipLaunchKernelGGL((abn_fit_spec_kernel<1, false, true, true>), grid, block, lds, st, a);
+    else if (rmax == 2) hipLaunchKernelGGL((abn_fit_spec_kernel<2, false, true, true>), grid, block, lds, st, a);
+    else if (rmax == 4) hipLaunchKernelGGL((abn_fit_spec_kernel<4, false, false, true>), grid, block, lds, st, a);
+    else hipLaunchKernelGGL((abn_fit_spec_kernel<8, false, false, true>), grid, block, lds, st, a);
+  } else if (dense) {
     if (a.strict) {
       if (rmax == 1) hipLaunchKernelGGL((abn_fit_spec_kernel<1, true, true>), grid, block, lds, st, a);
       else hipLaunchKernelGGL((abn_fit_spec_kernel<2, true, true>), grid, block, lds, st, a);

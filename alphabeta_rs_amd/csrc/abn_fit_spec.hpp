@@ -42,8 +42,12 @@ constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16 + 2 * kSpecPreDoub
 // DENSE (pedigrees of up to two rows per lane): compiled for FOUR workgroups per CU (128 registers, a few spilled) instead
 // of three — for launches of more chains than three per CU hold but no more than four (the reference's default 1000 starts /
 // 1000 bootstraps on 256 CUs): every chain resident at once instead of a second round of late starters.  Same code, same bits.
-template <int RMAX, bool STRICT = false, bool DENSE = false>
+// RESUME: the launch behind a time-sliced persistent launch that takes its parked tail up (FitArgs::spec_resume) — an
+// instantiation of its own so that the start-up path of the ordinary launches carries none of it (in the 128-register DENSE
+// build the extra live values cost spills: C2's phase B 1.60 -> 1.69 ms when it was a run-time branch).
+template <int RMAX, bool STRICT = false, bool DENSE = false, bool RESUME = false>
 __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void abn_fit_spec_kernel(const FitArgs a) {
+  static_assert(!RESUME || !STRICT, "the persistent kernel (whose tail this resumes) has no strict-order form");
   static_assert(!DENSE || RMAX <= 2, "four workgroups per CU: one or two rows per lane only");
   constexpr int G = kWave;
   extern __shared__ __align__(16) double lds[];
@@ -52,7 +56,7 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
   const int dim = gl & 3;
   const bool keeper = wv == 3;
   long long chain = blockIdx.x;         // grid = W*C exactly ...
-  if (a.spec_resume) {                  // ... or the tail of a persistent launch: slot b takes a parked chain up again
+  if constexpr (RESUME) {               // ... or the tail of a persistent launch: slot b takes a parked chain up again
     if ((int)blockIdx.x >= *a.susp_count) return;   // (uniform in the workgroup, before any barrier)
     chain = a.susp_list[blockIdx.x];
   }
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
   } else {
     // start simplex (starts: given; bootstraps: [params, vary() x4], src/boot_model.rs:69-75), handed to the
     // evaluation wavefronts through the (still unused) candidate table
-    if (a.spec_resume) {   // the sorted simplex as abn_fit_refill_kernel parked it at an iteration boundary
+    if constexpr (RESUME) {   // the sorted simplex as abn_fit_refill_kernel parked it at an iteration boundary
       const double* sp = a.state + (size_t)chain * 32;
 #pragma unroll
       for (int k = 0; k < 5; ++k) vx[k] = sp[4 * k + dim];
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
     return done;
   };
 
-  if (a.spec_resume) {
+  if constexpr (RESUME) {
     // a chain parked by the persistent kernel at an iteration boundary (IterState::update and the termination test of that
     // iteration are behind it: status < 0): costs, best vertex and counters as stored, then straight to the candidates
     if (keeper) {
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
   if (keeper) {
     if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
     if (gl == 0) {
-      if (a.spec_resume && a.slice_status) atomicAdd(a.slice_status + 1, 1u);  // the persistent launch's count of finished fits
+      if constexpr (RESUME) atomicAdd(a.slice_status + 1, 1u);  // the persistent launch's count of finished fits
       FitInfoDev fo;
       fo.best_cost = best_cost;
       fo.iters = iter;
