@@ -244,6 +244,15 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, int* kin
                       blocks > persist_waves_small(c);
   if (refill) blocks = persist_waves_for(c, blocks);
   if (!refill) a.quantum = 0;
+  // The quantum grows with the queue's depth (chains per lane group of the launch): a deep queue keeps the GPU full whatever
+  // the slicing, every park costs a wavefront ≈ 10 µs of dependent memory traffic, and the tail goes to the speculative
+  // kernel anyway; a shallow one needs short slices to start everybody early.  scripts/quantum_sweep.sh, profiles/r04_quantum_sweep.txt:
+  // C3 (1.2 chains per group) is best at 256, the C4 shard (2.0) at 256-384, the metaprofile shape (2.4) at 384-768, C4's
+  // 200 000 chains (16) at >= 1024.  Results do not depend on it (the persistent kernel is schedule-independent).
+  if (refill && a.quantum > 0) {
+    const long long q = (5LL * kQuantum * chains / (blocks * ng) / 8 + 63) & ~63LL;
+    a.quantum = (int)std::min<long long>(4LL * kQuantum, std::max<long long>(kQuantum, q));
+  }
 #ifdef ABN_MEASUREMENT_KNOBS  // scripts/prio_sweep.sh: wave priority by chain age, wavefronts and quantum of the persistent launch
   if (refill) {
     if (const char* e = getenv("ABN_PRIO")) sscanf(e, "%d,%d,%d,%d", &a.prio_mode, &a.prio_t[0], &a.prio_t[1], &a.prio_t[2]);
