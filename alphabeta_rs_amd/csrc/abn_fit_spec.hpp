@@ -51,7 +51,7 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
   static_assert(!DENSE || RMAX <= 2, "four workgroups per CU: one or two rows per lane only");
   constexpr int G = kWave;
   extern __shared__ __align__(16) double lds[];
-  const int wv = threadIdx.x >> 6;      // 0: reflection, 1: expansion, 2: contraction, 3: keeper
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: reflection, 1: expansion, 2: contraction, 3: keeper (a scalar: the role branches are uniform)
   const int gl = threadIdx.x & 63;
   const int dim = gl & 3;
   const bool keeper = wv == 3;
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
 #pragma unroll
       for (int k = 0; k < 5; ++k) tab[4 * k + dim] = vx[k];
     }
+    if (gl == 4) xch[3] = xch[7] = 0.0;  // the exchange buffers' fourth slot: the zero the done flag is compared with
   }
   __syncthreads();
 
@@ -143,9 +144,10 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
   const int mx_x = gl & 3, mx_y = gl >> 4;
   const bool mx_in = (mx_x < 3) && (mx_y < 3) && (((gl >> 2) & 3) == 0);
   const int preA_idx = mx_in ? 3 * mx_y + mx_x : 10, preB_idx = mx_in ? 3 * mx_x + mx_y : 10;  // [10] holds 0.0
-  auto eval = [&](double xd, bool pre) -> double {
+  // one evaluation of the candidate (al, be, wt, ic) — every lane holds all four; `pre`: preA / preB / prePen are this
+  // candidate's (then al and be are not looked at)
+  auto eval = [&](double al, double be, double wt, double ic, bool pre) -> double {
     ABN_STAMP(6);  // control flow + candidate fetch since the exchange
-    const double wt = dpp_mov<kDppQuadBcast2>(xd), ic = dpp_mov<kDppQuadBcast3>(xd);
     const double p_mm = wconst[1];
     const double sv0 = wconst[0], sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;
     double pen;
@@ -154,7 +156,6 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
       ABN_STAMP(0);
       build_power_table_mx_pre(preA, preB, a.T, pw, dtab, gl);
     } else {
-      const double al = dpp_mov<kDppQuadBcast0>(xd), be = dpp_mov<kDppQuadBcast1>(xd);
       const double puu = p_uu_est(al, be);
       const double dq = puu - wconst[2];
       pen = wconst[3] * (dq * dq);
@@ -213,26 +214,126 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
     return acc;
   };
 
-  // exchange: every evaluation wavefront publishes its cost, one workgroup barrier, everybody reads all three.
-  // The barrier also hands the keeper's LDS writes (candidate table, shrink points) to the others.
-  int phase = 0;
-  auto exchange = [&](double f, double& f0, double& f1, double& f2) {
-    double* buf = xch + 4 * phase;
-    if (!keeper && gl == 0) buf[wv] = f;
-    __syncthreads();
-    f0 = buf[0];
-    f1 = buf[1];
-    f2 = buf[2];
-    phase ^= 1;  // the other buffer next time: no second barrier needed
-    ABN_STAMP(4);
-  };
+  // ---- control block (LDS, two buffers): what the evaluation wavefronts need to follow the keeper's control flow — the five
+  // sorted costs BEFORE the running iteration (their decision needs c0..c4) and a `done` flag.  The keeper writes ctl[cb]
+  // while the others evaluate; they read it behind the next exchange barrier, then everybody flips cb.  The flag therefore
+  // reaches them one evaluation late: a finished fit costs one surplus evaluation (never counted, never used), and no
+  // iteration has the cost insertion or the termination test on the evaluation wavefronts' path.
+  double* ctl = gtab + 2 * kSpecPreDoubles;
 
-  // ---- control state (the keeper's; the evaluation wavefronts hold a published copy of the costs in c[])
+  // =================================================================================================================
+  // The two roles run their own loops (the role is a scalar: no lane masks, no values merged between them); what keeps
+  // them in step is the barrier count, the same on both sides of every path:
+  //   start: [Solver::init: 2 exchanges]  hand-over (1)
+  //   per iteration: exchange (1); a shrink adds: points (1), 2 exchanges, hand-over (1)
+  //   end: the keeper, finished after iteration i, meets the others at the exchange of their surplus evaluation i + 1.
+  // Exchange = the evaluation wavefronts write their cost to xch[4 phase + wavefront], barrier, the keeper reads; two
+  // buffers, so no second barrier.  Hand-over of a freshly sorted simplex (after Solver::init, after a shrink, after a
+  // resume): the keeper writes the control block and, unless the fit is finished, the three candidates with their
+  // prepared inputs; barrier; the others learn `done` and pick their candidate up.
+  // =================================================================================================================
+  if (!keeper) {
+    int phase = 0, cb = 0, par = 0;
+    double wt = 0.0, ic = 0.0, al = 0.0, be = 0.0;
+    auto put = [&](double f) {
+      if (gl == 0) xch[4 * phase + wv] = f;
+      __syncthreads();
+      phase ^= 1;
+    };
+    auto eval_point = [&](const double* x) { return eval(x[0], x[1], x[2], x[3], false); };
+    // the candidate of outcome slot o for this wavefront: weight and intercept (every lane reads the same addresses), the
+    // prepared inputs; al / be only where the matrix instruction is compiled out
+    auto fetch = [&](int o) {
+      const double* t = tab + par * kSpecTabDoubles + o * 12 + 4 * wv;
+      const double* g = gtab + par * kSpecPreDoubles + (o * 3 + wv) * 12;
+      wt = t[2];
+      ic = t[3];
+      if constexpr (kMatrixFma) {
+        preA = g[preA_idx];
+        preB = g[preB_idx];
+        prePen = g[9];
+      } else {
+        al = t[0];
+        be = t[1];
+      }
+    };
+    auto pickup = [&]() -> bool {
+      __syncthreads();
+      const bool d = ctl[8 * cb + 5] != 0.0;
+      if (!d) fetch(0);
+      par ^= 1;
+      return d;
+    };
+    if constexpr (!RESUME) {  // Solver::init: the five start costs in input order (3 + 2)
+      put(eval_point(tab + 4 * wv));
+      put(eval_point(tab + 4 * (wv == 0 ? 3 : 4)));
+    }
+    bool done = pickup();
+    // The decision of NelderMead::next_iter on the evaluation wavefronts — the critical path: their next evaluation waits
+    // for it.  The twelve comparisons it can ask for are independent of each other, so lane j < 11 loads ONE pair (X, Y) of
+    // published numbers behind the barrier and two v_cmp_f64 of the whole wavefront produce all of them as bits of two
+    // scalar masks (X = cost cmp_x of the exchange buffer — reflection, expansion, contraction; [3] holds 0.0 —, Y = sorted
+    // cost cmp_y, the reflection cost (-1) or the done flag (5)):
+    //   lane 0..3 (r,c3) (r,c2) (r,c1) (r,c0)   4..7 (c,c3) (c,c2) (c,c1) (c,c0)   8 (c,c4)   9 (e,r)   10 (0,done)
+    // so that the rank of an accepted cost — insert_tail<4>'s stable insertion: b3 = f < c3, b2 = b3 && f < c2, ... — is the
+    // length of the run of ones from bit 0 (reflection) or bit 4 (contraction).  ≈ 25 scalar instructions instead of a
+    // ladder of vector compares and branches with every lane holding every cost (650 of an iteration's 3 700 cycles).
+    const int cmp_x = gl < 11 ? (int)((0x31222220000ull >> (4 * gl)) & 0xfull) : 0;
+    const int cmp_y = gl < 11 ? (int)((0x60512341234ull >> (4 * gl)) & 0xfull) - 1 : 4;
+    while (!done) {
+      const double f = eval(al, be, wt, ic, true);
+      double* buf = xch + 4 * phase;
+      if (gl == 0) buf[wv] = f;
+      const double* px = buf + cmp_x;
+      const double* py = cmp_y < 0 ? buf : ctl + 8 * cb + cmp_y;
+      __syncthreads();
+      const double X = *px, Y = *py;
+      phase ^= 1;
+      const uint32_t lt = (uint32_t)__builtin_amdgcn_fcmp(X, Y, 4 /* ordered < */);
+      const uint32_t ge = (uint32_t)__builtin_amdgcn_fcmp(X, Y, 3 /* ordered >= */);
+      ABN_STAMP(4);
+#ifdef ABN_STAMPS
+      ++seg[7];  // iterations seen by this wavefront
+#endif
+      if (lt & 0x400u) break;  // the keeper finished the fit while this (then surplus) evaluation ran
+      cb ^= 1;
+      const int o_r = 4 - __builtin_ctz(~lt | 0x10u), o_c = 9 - __builtin_ctz((~lt >> 4) | 0x10u);
+      const uint32_t is_r = lt & (ge >> 3) & 1u;   // reflection accepted: r < c3 && r >= c0
+      const uint32_t is_e = (lt >> 3) & 1u;        // else expansion tried: r < c0 — the better of the two goes in
+      const uint32_t is_c = ge & 1u;               // else contraction tried: r >= c3; else: NaN reflection cost
+      const int o_e = (lt & 0x200u) ? 4 : o_r;
+      const int o = is_r ? o_r : (is_e ? o_e : o_c);
+      if ((is_r | is_e | (is_c & (lt >> 8))) & 1u) {   // a point is accepted: outcome slot o
+        fetch(o);
+        par ^= 1;
+        ABN_STAMP(5);  // decision
+      } else if (is_c && a.shrink_variant == 0) {
+        par ^= 1;  // rejected contraction, argmin 0.8.1: the simplex stays as it is — the same candidates again
+      } else {     // NelderMead::shrink: vertices 1..4 re-evaluated in order (3 + 1)
+        __syncthreads();
+        put(eval_point(pts + 4 * wv));
+        put(eval_point(pts + 12));
+        done = pickup();
+      }
+    }
+#ifdef ABN_STAMPS
+    if (a.dbg && chain == 0 && wv == 0 && gl == 0) {
+      for (int q = 0; q < 8; ++q) a.dbg[q] = seg[q];
+      a.dbg[7] = seg[7];
+    }
+#endif
+    return;
+  }
+
+  // =================================================================================================================
+  // the keeper
+  // =================================================================================================================
+  int phase = 0, cb = 0, par = 0;
   double c[5], best_cost = __builtin_inf();
   bool have_best = false;
   int iter = 0;
   // IterState::update() + terminate_internal(): -1 = go on, else the ABN_FIT_* status.  `improved`: the best
-  // vertex is the new best_param (the keeper copies it)
+  // vertex is the new best_param
   auto ctl_begin = [&](bool count_iter, bool& improved) -> int {
     const double c_best = c[0];
     improved = c_best < best_cost || (__builtin_isinf(c_best) && __builtin_isinf(best_cost) &&
@@ -258,19 +359,15 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
     else if (best_cost <= -__builtin_inf()) status = 3;
     return status;
   };
-
-  // ---- keeper state: the simplex, this lane's dimension of the five vertices in rank order, the three
-  // candidates of the running iteration, best_param, evaluation count
+  // the three candidates of the running iteration (this lane's dimension), best_param, evaluation count
   double xr = 0.0, x_e = 0.0, x_c = 0.0, bx = __builtin_nan("");
   int evals = 0;
-  // the keeper's lane group: quad q < 10 works on outcome q = (accepted point, rank): r@0..3, e@0, c@0..4
+  // quad q < 10 of the keeper works on outcome q = (accepted point, rank): r@0..3, e@0, c@0..4
   const int oq = gl >> 2;
   const int o_kind = oq < 4 ? 0 : (oq == 4 ? 1 : 2);
   const int o_rank = oq < 4 ? oq : (oq == 4 ? 0 : oq - 5);
-
-  // keeper: generation matrix and penalty term of the three candidates (r_, e_, c_: this lane's dimension) of
-  // outcome slot `oq` — lane (quad, dimension t < 3) works for candidate t; same functions as the evaluation
-  // wavefronts would call, so the same bits
+  // generation matrix and penalty term of the three candidates (r_, e_, c_: this lane's dimension) of outcome slot `oq` —
+  // lane (quad, dimension t < 3) works for candidate t; same functions as an evaluation would call, so the same bits
   auto emit_pre = [&](double r_, double e_, double c_, int parity) {
     const double ar = dpp_mov<kDppQuadBcast0>(r_), br = dpp_mov<kDppQuadBcast1>(r_);
     const double ae = dpp_mov<kDppQuadBcast0>(e_), be = dpp_mov<kDppQuadBcast1>(e_);
@@ -296,106 +393,70 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
       g[10] = 0.0;
     }
   };
-  // evaluation wavefronts: the prepared inputs of candidate (outcome o, this wavefront) next to the candidate itself
-  auto fetch_pre = [&](int o, int parity) {
-    const double* g = gtab + parity * kSpecPreDoubles + (o * 3 + wv) * 12;
-    preA = g[preA_idx];
-    preB = g[preB_idx];
-    prePen = g[9];
-  };
-
-  // ---- The keeper alone keeps the optimiser's state.  What the evaluation wavefronts need to follow the control
-  // flow it publishes in `ctl` (two buffers): the five sorted costs BEFORE the running iteration (their decision
-  // needs c0, c3, c4 and the rank of the accepted cost) and a `done` flag.  The keeper writes ctl[cb] while the
-  // others evaluate; they read it behind the next exchange barrier, then everybody flips cb.  The flag therefore
-  // reaches them one evaluation late: a finished fit costs one surplus evaluation (never counted, never used),
-  // every iteration saves the cost insertion and the termination test on the evaluation wavefronts' path.
-  double* ctl = gtab + 2 * kSpecPreDoubles;
-  int cb = 0;
-  auto ctl_write = [&](int status_now) {      // keeper
+  auto ctl_write = [&](int status_now) {
     if (gl < 5) ctl[8 * cb + gl] = gl == 0 ? c[0] : (gl == 1 ? c[1] : (gl == 2 ? c[2] : (gl == 3 ? c[3] : c[4])));
     if (gl == 5) ctl[8 * cb + 5] = status_now >= 0 ? 1.0 : 0.0;
   };
+  auto take = [&](double& f0, double& f1, double& f2) {
+    const double* buf = xch + 4 * phase;
+    __syncthreads();
+    f0 = buf[0];
+    f1 = buf[1];
+    f2 = buf[2];
+    phase ^= 1;
+  };
   bool improved;
   int status = -1;
-  int par = 0;
   double f0, f1, f2;
-  double cand = 0.0;
-
-  // hand-over of a freshly sorted simplex (after Solver::init and after a shrink): the keeper writes the control
-  // block and, unless the fit is finished, the three candidates with their prepared inputs; one barrier; the
-  // evaluation wavefronts learn `done` and pick their candidate up.  Returns done.
   auto publish = [&]() -> bool {
-    if (keeper) {
-      ctl_write(status);
-      if (status < 0) {  // centroid (p0 + p1 + p2 + p3) * (1/4), x0 + (x0 - xw) * alpha, x0 + (xr - x0) * gamma, x0 + (xw - x0) * rho
-        double acc = vx[0];
-        acc = acc + vx[1];
-        acc = acc + vx[2];
-        acc = acc + vx[3];
-        const double x0 = acc * (1.0 / 4.0);
-        xr = x0 + (x0 - vx[4]) * 1.0;
-        x_e = x0 + (xr - x0) * 2.0;
-        x_c = x0 + (vx[4] - x0) * 0.5;
-        if (gl < 4) {
-          double* t = tab + par * kSpecTabDoubles;
-          t[dim] = xr;
-          t[4 + dim] = x_e;
-          t[8 + dim] = x_c;
-        }
-        if constexpr (kMatrixFma) emit_pre(xr, x_e, x_c, par);  // every quad writes its slot; slot 0 is read
+    ctl_write(status);
+    if (status < 0) {  // centroid (p0 + p1 + p2 + p3) * (1/4), x0 + (x0 - xw) * alpha, x0 + (xr - x0) * gamma, x0 + (xw - x0) * rho
+      double acc = vx[0];
+      acc = acc + vx[1];
+      acc = acc + vx[2];
+      acc = acc + vx[3];
+      const double x0 = acc * (1.0 / 4.0);
+      xr = x0 + (x0 - vx[4]) * 1.0;
+      x_e = x0 + (xr - x0) * 2.0;
+      x_c = x0 + (vx[4] - x0) * 0.5;
+      if (gl < 4) {
+        double* t = tab + par * kSpecTabDoubles;
+        t[dim] = xr;
+        t[4 + dim] = x_e;
+        t[8 + dim] = x_c;
       }
+      if constexpr (kMatrixFma) emit_pre(xr, x_e, x_c, par);  // every quad writes its slot; slot 0 is read
     }
     __syncthreads();
-    bool done = status >= 0;                  // keeper
-    if (!keeper) {
-      done = ctl[8 * cb + 5] != 0.0;
-      if (!done) {
-        cand = tab[par * kSpecTabDoubles + 4 * wv + dim];
-        if constexpr (kMatrixFma) fetch_pre(0, par);
-      }
-    }
     par ^= 1;
-    return done;
+    return status >= 0;
   };
 
   if constexpr (RESUME) {
     // a chain parked by the persistent kernel at an iteration boundary (IterState::update and the termination test of that
     // iteration are behind it: status < 0): costs, best vertex and counters as stored, then straight to the candidates
-    if (keeper) {
-      const double* sp = a.state + (size_t)chain * 32;
+    const double* sp = a.state + (size_t)chain * 32;
 #pragma unroll
-      for (int k = 0; k < 5; ++k) c[k] = sp[20 + k];
-      bx = sp[25 + dim];
-      best_cost = sp[29];
-      const long long ie = __double_as_longlong(sp[30]);
-      iter = (int)(ie & 0xffffffffll);
-      evals = (int)(ie >> 32);
-      have_best = __double_as_longlong(sp[31]) != 0;
-      status = -1;
-    }
+    for (int k = 0; k < 5; ++k) c[k] = sp[20 + k];
+    bx = sp[25 + dim];
+    best_cost = sp[29];
+    const long long ie = __double_as_longlong(sp[30]);
+    iter = (int)(ie & 0xffffffffll);
+    evals = (int)(ie >> 32);
+    have_best = __double_as_longlong(sp[31]) != 0;
   } else {
-    // ---- Solver::init: the five start costs in input order (3 + 2), stable sort, first termination check
-    cand = keeper ? 0.0 : tab[4 * wv + dim];
-    exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
-    c[0] = f0;
-    c[1] = f1;
-    c[2] = f2;
-    cand = keeper ? 0.0 : tab[4 * (wv == 0 ? 3 : 4) + dim];
-    exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
-    c[3] = f0;
-    c[4] = f1;
+    // Solver::init: the five start costs in input order (3 + 2), stable sort, first termination check
+    take(c[0], c[1], c[2]);
+    take(c[3], c[4], f2);
     evals = 5;
-    if (keeper) {
-      sort5(c, vx);
-      status = ctl_begin(false, improved);
-      if (improved) bx = vx[0];
-    }
+    sort5(c, vx);
+    status = ctl_begin(false, improved);
+    if (improved) bx = vx[0];
   }
   bool done = publish();
 
   while (!done) {
-    if (keeper) {
+    {
       // the candidates of the NEXT iteration for each way this one can end.  Outcome (A, p): the accepted
       // point A replaces the worst vertex and sorts in at rank p; the new order is v0..v3 with A at p.
       const double A = o_kind == 0 ? xr : (o_kind == 1 ? x_e : x_c);
@@ -421,42 +482,9 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
       if constexpr (kMatrixFma) emit_pre(nr, ne, nc, par);
     }
     double fr, fe, fc;
-    {  // exchange + (evaluation wavefronts) the control block, read in ONE batch of LDS loads behind the barrier:
-       // the sorted costs before this iteration, and whether the keeper finished the fit while this (then surplus)
-       // evaluation ran
-      const double f = keeper ? 0.0 : eval(cand, true);
-      double* buf = xch + 4 * phase;
-      if (!keeper && gl == 0) buf[wv] = f;
-      __syncthreads();
-      const double* b = ctl + 8 * cb;
-      fr = buf[0];
-      fe = buf[1];
-      fc = buf[2];
-      double k0 = c[0], k1 = c[1], k2 = c[2], k3 = c[3], k4 = c[4], dn = 0.0;
-      if (!keeper) {
-        k0 = b[0];
-        k1 = b[1];
-        k2 = b[2];
-        k3 = b[3];
-        k4 = b[4];
-        dn = b[5];
-      }
-      c[0] = k0;
-      c[1] = k1;
-      c[2] = k2;
-      c[3] = k3;
-      c[4] = k4;
-      phase ^= 1;
-      ABN_STAMP(4);
-#ifdef ABN_STAMPS
-      ++seg[7];  // iterations seen by this wavefront
-#endif
-      if (dn != 0.0) break;
-    }
+    take(fr, fe, fc);
     cb ^= 1;
     // ---- NelderMead::next_iter's decision.  Every lane holds the same costs, so the branches are uniform.
-    // (Measured alternatives, all slower on a lone wavefront: the costs in scalar registers via v_readfirstlane —
-    // persistent: SGPR spills; re-read every iteration: +23 % —, and the flat predicated form of abn_fit_kernel.)
     int kind, which = 0;   // kind 0: a point is accepted, 1: rejected contraction (simplex untouched), 2: shrink
     double fi = fr;
     int spent;             // cost() calls the reference makes in this branch
@@ -489,97 +517,71 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
       const int p = 4 - ((b3 ? 1 : 0) + (b2 ? 1 : 0) + (b1 ? 1 : 0) + (b0 ? 1 : 0));
       const int o = which == 0 ? p : (which == 1 ? 4 : 5 + p);
       const double* t = tab + par * kSpecTabDoubles + o * 12;
-      if (keeper) {
-        c[4] = fi;
-        vx[4] = which == 0 ? xr : (which == 1 ? x_e : x_c);
-        insert_tail<4>(c, vx);
-        status = ctl_begin(true, improved);
-        if (improved) bx = vx[0];
-        ctl_write(status);
-        xr = t[dim];
-        x_e = t[4 + dim];
-        x_c = t[8 + dim];
-      } else {
-        cand = t[4 * wv + dim];
-        if constexpr (kMatrixFma) fetch_pre(o, par);
-        ABN_STAMP(5);  // decision
-      }
+      c[4] = fi;
+      vx[4] = which == 0 ? xr : (which == 1 ? x_e : x_c);
+      insert_tail<4>(c, vx);
+      status = ctl_begin(true, improved);
+      if (improved) bx = vx[0];
+      ctl_write(status);
+      xr = t[dim];
+      x_e = t[4 + dim];
+      x_c = t[8 + dim];
       par ^= 1;
     } else if (kind == 1) {
       // argmin 0.8.1: a rejected contraction leaves the simplex untouched — for good: every later iteration
       // repeats this one.  no_skip == 0: finish the chain with the counters it would reach (FitArgs::no_skip)
-      if (keeper) {
-        if (a.no_skip == 0) {
-          const int rest = a.max_iters - iter - 1;
-          evals += 2 * rest;
-          iter += rest;
-          if (a.skipped && gl == 0 && rest > 0) atomicAdd(a.skipped, 2ull * (unsigned long long)rest);
-        }
-        status = ctl_begin(true, improved);
-        ctl_write(status);
+      if (a.no_skip == 0) {
+        const int rest = a.max_iters - iter - 1;
+        evals += 2 * rest;
+        iter += rest;
+        if (a.skipped && gl == 0 && rest > 0) atomicAdd(a.skipped, 2ull * (unsigned long long)rest);
       }
-      par ^= 1;  // same candidates again; the keeper rebuilds the (identical) tables in the other buffers
+      status = ctl_begin(true, improved);
+      ctl_write(status);
+      par ^= 1;  // same candidates again; the (identical) tables are rebuilt in the other buffers
     } else {
       // NelderMead::shrink (NaN reflection cost, or the textbook variant after a rejected contraction):
       // vertices 1..4 move towards the best by sigma and are re-evaluated in order (3 + 1)
-      if (keeper) {
 #pragma unroll
-        for (int k = 1; k < 5; ++k) {
-          vx[k] = vx[0] + (vx[k] - vx[0]) * 0.5;
-          if (gl < 4) pts[4 * (k - 1) + dim] = vx[k];
-        }
+      for (int k = 1; k < 5; ++k) {
+        vx[k] = vx[0] + (vx[k] - vx[0]) * 0.5;
+        if (gl < 4) pts[4 * (k - 1) + dim] = vx[k];
       }
       __syncthreads();
-      if (!keeper) cand = pts[4 * wv + dim];
-      exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
-      c[1] = f0;
-      c[2] = f1;
-      c[3] = f2;
-      if (!keeper) cand = pts[12 + dim];
-      exchange(keeper ? 0.0 : eval(cand, false), f0, f1, f2);
-      c[4] = f0;
+      take(c[1], c[2], c[3]);
+      take(c[4], f1, f2);
       evals += 4;
-      if (keeper) {
-        sort5(c, vx);
-        status = ctl_begin(true, improved);
-        if (improved) bx = vx[0];
-      }
+      sort5(c, vx);
+      status = ctl_begin(true, improved);
+      if (improved) bx = vx[0];
       done = publish();
       continue;
     }
-    // the keeper found the fit finished: the others are one evaluation ahead — meet them at that exchange
-    if (keeper && status >= 0) {
-      exchange(0.0, f0, f1, f2);
+    // the fit is finished: the others are one evaluation ahead — meet them at that exchange
+    if (status >= 0) {
+      __syncthreads();
       break;
     }
   }
 
-#ifdef ABN_STAMPS
-  if (a.dbg && chain == 0 && wv == 0 && gl == 0) {
-    for (int q = 0; q < 8; ++q) a.dbg[q] = seg[q];
-    a.dbg[7] = seg[7];
-  }
-#endif
   const double b0 = dpp_mov<kDppQuadBcast0>(bx), b1 = dpp_mov<kDppQuadBcast1>(bx);
-  if (keeper) {
-    if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
-    if (gl == 0) {
-      if constexpr (RESUME) atomicAdd(a.slice_status + 1, 1u);  // the persistent launch's count of finished fits
-      FitInfoDev fo;
-      fo.best_cost = best_cost;
-      fo.iters = iter;
-      fo.evals = evals;
-      fo.status = have_best ? status : 2;
-      fo.lanes = a.tree;
-      a.info[chain] = fo;
-    }
-    if (a.raw) {
-      double* ro = a.raw + (size_t)chain * 7;
-      if (gl < 4) ro[gl] = bx;
-      if (gl == 4) ro[4] = est_mm(b0, b1);
-      if (gl == 5) ro[5] = est_um(b0, b1);
-      if (gl == 6) ro[6] = p_uu_est(b0, b1);
-    }
+  if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
+  if (gl == 0) {
+    if constexpr (RESUME) atomicAdd(a.slice_status + 1, 1u);  // the persistent launch's count of finished fits
+    FitInfoDev fo;
+    fo.best_cost = best_cost;
+    fo.iters = iter;
+    fo.evals = evals;
+    fo.status = have_best ? status : 2;
+    fo.lanes = a.tree;
+    a.info[chain] = fo;
+  }
+  if (a.raw) {
+    double* ro = a.raw + (size_t)chain * 7;
+    if (gl < 4) ro[gl] = bx;
+    if (gl == 4) ro[4] = est_mm(b0, b1);
+    if (gl == 5) ro[5] = est_um(b0, b1);
+    if (gl == 6) ro[6] = p_uu_est(b0, b1);
   }
 }
 
