@@ -267,16 +267,20 @@ static int launch_fit(abn_ctx* c, FitArgs a, int lanes, hipStream_t st, int* kin
     if (const char* e = getenv("ABN_DROP_FIFO_ENTRY")) a.drop_entry = atoi(e);
   }
 #endif
-  // Tail hand-over (FitArgs::tail_cap): the last chains of a time-sliced launch — as many as abn_fit_spec_kernel keeps resident
-  // — finish on four wavefronts each instead of one by one on an emptying GPU at the packed kernel's step time
-  // (metaprofile shape, phase A: 12 of 17 ms were such a tail).  Needs the speculative kernel to apply to the pedigree.
+  // Tail hand-over (FitArgs::tail_cap): the last chains of a time-sliced launch finish on four wavefronts each instead of one
+  // by one on an emptying GPU at the packed kernel's step time (metaprofile shape, phase A: 12 of 17 ms were such a tail).
+  // As many as abn_fit_spec_kernel keeps resident (four per CU at up to two rows per lane), twice that behind the deep queues
+  // of the 12-wavefronts-per-CU geometry, where the later workgroups start as the first end (scripts/tail_sweep.sh,
+  // profiles/r04_tail_sweep.txt: C3 is best at 1024, the C4 shard and the metaprofile shape at 2048-3072: +3 % / +2 %).
+  // Needs the speculative kernel to apply to the pedigree.
   a.tail_cap = 0;
   if (refill && a.quantum > 0 && a.slice_status && a.susp_list && a.tree == kTreeCanon) {
     FitArgs probe = a0;
     probe.tree = kTreeCanon;
-    if (spec_applicable(probe)) a.tail_cap = (int)((pick_rmax(a.N, kWave) <= 2 ? 4LL : 2LL) * c->cus);
+    if (spec_applicable(probe))
+      a.tail_cap = (int)((pick_rmax(a.N, kWave) <= 2 ? (blocks == persist_waves(c) ? 8LL : 4LL) : 2LL) * c->cus);
 #ifdef ABN_MEASUREMENT_KNOBS
-    if (const char* e = getenv("ABN_TAIL_CAP")) a.tail_cap = std::min(a.tail_cap, std::max(0, atoi(e)));
+    if (const char* e = getenv("ABN_TAIL_CAP")) a.tail_cap = a.tail_cap > 0 ? (int)std::min<long long>(chains, std::max(0, atoi(e))) : 0;
 #endif
     a.susp_count = reinterpret_cast<int*>(a.slice_status + 3);
   }
@@ -325,10 +329,10 @@ static bool fit_streams(int n, int chain_stride, int lanes, int strict) {
 
 // Speculative kernel (phase A; three evaluation wavefronts + a bookkeeping wavefront per chain): resident mode
 // with one wavefront per candidate only.
-// Chains up to which the speculative kernel is used: 4/3 of what the GPU holds at once (three workgroups per CU
-// for pedigrees of up to two rows per lane, else two: the kernel's register budget).  Measured (scripts/phase_a_sweep.py,
-// C3 topology): 1000 chains 2.6 ms against 3.2 ms with one wavefront per chain, 1500 chains 4.2 against 3.4; the
-// 351-row golden pedigree with 1000 bootstraps: 2.8 ms against 2.0 ms.
+// Chains up to which the speculative kernel is used: what the GPU holds at once for pedigrees of up to two rows per lane
+// (four workgroups per CU), two thirds of that beyond.  Measured when the kernel held three / two per CU and an iteration
+// took 3 700 cycles (scripts/phase_a_sweep.py, C3 topology): 1000 chains 2.6 ms against 3.2 ms with one wavefront per
+// chain, 1500 chains 4.2 against 3.4; the 351-row golden pedigree with 1000 bootstraps: 2.8 ms against 2.0 ms.
 static long long spec_max_chains(const abn_ctx* c, int n_rows) {
   const long long mx = kPhaseASpecPerCu * c->cus;
   return pick_rmax(n_rows, kWave) <= 2 ? mx : mx * 2 / 3;
@@ -362,24 +366,12 @@ static int launch_fit_spec(abn_ctx* c, FitArgs a, hipStream_t st) {
   const size_t lds = (3 * (size_t)a.chain_stride + kSpecCommDoubles) * sizeof(double);
   dim3 grid((unsigned)chains), block(4 * kWave);
   a.tree = a.strict ? 1 : kTreeCanon;  // spec_applicable admitted it
-  // more chains than three workgroups per CU hold, at most four per CU (spec_max_chains), one or two rows per lane: the
-  // build of the kernel for four workgroups per CU keeps them all resident (C2's 1000 bootstraps: 1.65 -> 1.60 ms; the reference default -i 1000 on the C3 pedigree: 519 k -> 565 k fits/s, profiles/r04_spec_dense_ab.txt)
-  bool dense = rmax <= 2 && chains > 3LL * c->cus && lds * 4 <= c->lds_per_cu;
-#ifdef ABN_MEASUREMENT_KNOBS
-  if (const char* e = getenv("ABN_SPEC_DENSE")) dense = dense && atoi(e) != 0;
-#endif
-  if (a.spec_resume) {  // the tail of a persistent launch (never strict): dense where it exists
-    if (rmax == 1) hipLaunchKernelGGL((abn_fit_spec_kernel<1, false, true, true>), grid, block, lds, st, a);
-    else if (rmax == 2) hipLaunchKernelGGL((abn_fit_spec_kernel<2, false, true, true>), grid, block, lds, st, a);
-    else if (rmax == 4) hipLaunchKernelGGL((abn_fit_spec_kernel<4, false, false, true>), grid, block, lds, st, a);
-    else hipLaunchKernelGGL((abn_fit_spec_kernel<8, false, false, true>), grid, block, lds, st, a);
-  } else if (dense) {
-    if (a.strict) {
-      if (rmax == 1) hipLaunchKernelGGL((abn_fit_spec_kernel<1, true, true>), grid, block, lds, st, a);
-      else hipLaunchKernelGGL((abn_fit_spec_kernel<2, true, true>), grid, block, lds, st, a);
-    } else {
-      if (rmax == 1) hipLaunchKernelGGL((abn_fit_spec_kernel<1, false, true>), grid, block, lds, st, a);
-      else hipLaunchKernelGGL((abn_fit_spec_kernel<2, false, true>), grid, block, lds, st, a);
+  if (a.spec_resume) {  // the tail of a persistent launch (never strict)
+    switch (rmax) {
+      case 1: hipLaunchKernelGGL((abn_fit_spec_kernel<1, false, true>), grid, block, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((abn_fit_spec_kernel<2, false, true>), grid, block, lds, st, a); break;
+      case 4: hipLaunchKernelGGL((abn_fit_spec_kernel<4, false, true>), grid, block, lds, st, a); break;
+      default: hipLaunchKernelGGL((abn_fit_spec_kernel<8, false, true>), grid, block, lds, st, a); break;
     }
   } else if (a.strict) {
     switch (rmax) {

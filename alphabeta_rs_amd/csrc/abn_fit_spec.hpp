@@ -39,16 +39,13 @@ constexpr int kSpecCommDoubles = 8 + 2 * kSpecTabDoubles + 16 + 2 * kSpecPreDoub
 
 // STRICT (abn_options.strict_order): the evaluation wavefronts sum the residuals serially in row order (terms to LDS, N
 // more doubles per wavefront, then serial_sum_lds) — the reference's order, the oracle's lanes = 1.
-// DENSE (pedigrees of up to two rows per lane): compiled for FOUR workgroups per CU (128 registers, a few spilled) instead
-// of three — for launches of more chains than three per CU hold but no more than four (the reference's default 1000 starts /
-// 1000 bootstraps on 256 CUs): every chain resident at once instead of a second round of late starters.  Same code, same bits.
+// Registers: 88-135 per lane (the roles' loops are separate, so neither carries the other's state): four workgroups per CU for
+// pedigrees of up to two rows per lane — 1024 chains resident on the MI355X —, three beyond.
 // RESUME: the launch behind a time-sliced persistent launch that takes its parked tail up (FitArgs::spec_resume) — an
-// instantiation of its own so that the start-up path of the ordinary launches carries none of it (in the 128-register DENSE
-// build the extra live values cost spills: C2's phase B 1.60 -> 1.69 ms when it was a run-time branch).
-template <int RMAX, bool STRICT = false, bool DENSE = false, bool RESUME = false>
-__global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void abn_fit_spec_kernel(const FitArgs a) {
+// instantiation of its own so that the start-up path of the ordinary launches carries none of it.
+template <int RMAX, bool STRICT = false, bool RESUME = false>
+__global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 4 : 3) void abn_fit_spec_kernel(const FitArgs a) {
   static_assert(!RESUME || !STRICT, "the persistent kernel (whose tail this resumes) has no strict-order form");
-  static_assert(!DENSE || RMAX <= 2, "four workgroups per CU: one or two rows per lane only");
   constexpr int G = kWave;
   extern __shared__ __align__(16) double lds[];
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // 0: reflection, 1: expansion, 2: contraction, 3: keeper (a scalar: the role branches are uniform)
@@ -407,7 +404,7 @@ __global__ __launch_bounds__(4 * kWave, DENSE ? 4 : (RMAX <= 2 ? 3 : 2)) void ab
   };
   bool improved;
   int status = -1;
-  double f0, f1, f2;
+  double f1, f2;
   auto publish = [&]() -> bool {
     ctl_write(status);
     if (status < 0) {  // centroid (p0 + p1 + p2 + p3) * (1/4), x0 + (x0 - xw) * alpha, x0 + (xr - x0) * gamma, x0 + (xw - x0) * rho

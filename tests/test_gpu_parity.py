@@ -817,7 +817,7 @@ def test_persistent_refill_kernel_is_schedule_independent(abn, gpu_ctx, golden, 
         handed = plan.tail_handed()
         plan.close()
         if groups == 1:   # round 4: the last chains of the time-sliced launch finish on the speculative kernel (same bits)
-            assert 0 < handed[1] <= 1024, handed
+            assert 0 < handed[1] <= 2048, handed   # at most 8 per CU (the 12-wavefronts-per-CU geometry of this launch)
         else:
             assert handed == (0, 0), handed
     lanes = int(outs[0]["info_b"]["lanes"][0, 0])          # the canonical tree code, whatever the packed lane count
