@@ -110,7 +110,7 @@ static long long persist_waves_for(const abn_ctx* c, long long blocks) {
 #ifndef ABN_PHASE_A_SPEC_PER_CU
 #define ABN_PHASE_A_SPEC_PER_CU 4
 #endif
-constexpr long long kPhaseASpecPerCu = ABN_PHASE_A_SPEC_PER_CU;  // start chains up to which phase A uses abn_fit_spec_kernel (1024)
+constexpr long long kPhaseASpecPerCu = ABN_PHASE_A_SPEC_PER_CU;  // chains per CU abn_fit_spec_kernel keeps resident at up to two rows per lane (spec_max_chains)
 constexpr long long kPhaseAWidePerCu = 24;                      // ... and up to which it uses one wavefront per chain (6144)
 // Time slicing of persistent launches (FitArgs::quantum): evaluations a chain runs before it yields to waiting chains.
 #ifndef ABN_QUANTUM
@@ -329,13 +329,15 @@ static bool fit_streams(int n, int chain_stride, int lanes, int strict) {
 
 // Speculative kernel (phase A; three evaluation wavefronts + a bookkeeping wavefront per chain): resident mode
 // with one wavefront per candidate only.
-// Chains up to which the speculative kernel is used: what the GPU holds at once for pedigrees of up to two rows per lane
-// (four workgroups per CU), two thirds of that beyond.  Measured when the kernel held three / two per CU and an iteration
-// took 3 700 cycles (scripts/phase_a_sweep.py, C3 topology): 1000 chains 2.6 ms against 3.2 ms with one wavefront per
-// chain, 1500 chains 4.2 against 3.4; the 351-row golden pedigree with 1000 bootstraps: 2.8 ms against 2.0 ms.
+// Chains up to which the speculative kernel is used: 1.5 x what the GPU holds at once for pedigrees of up to two rows per
+// lane (four workgroups per CU -> 1536 chains on the MI355X), what it holds beyond (three per CU -> 768).  Phase-B time,
+// speculative / one wavefront per chain / packed (scripts/b_kernel_sweep.py, profiles/r04_b_kernel_sweep.txt): C3 topology
+// 1000 chains 0.76 / 1.03 / 1.60 ms, 1500: 1.04 / 1.15 / 1.16, 2000: 1.28 / 1.31 / 1.31, 3000: 1.70 / 1.49 / 1.48; the bundled
+// 6-row pedigree 1500: 1.44 / 1.95 / 1.95, 3000: 1.95 / 2.43 / 2.26; the 351-row golden pedigree 500: 1.21 / 1.95 / 1.95,
+// 1000: 2.14 / 1.97 / 1.96.  Phase A (scripts/phase_a_sweep.py, C3 topology): 1000 chains 1.94 ms against 3.18 ms.
 static long long spec_max_chains(const abn_ctx* c, int n_rows) {
   const long long mx = kPhaseASpecPerCu * c->cus;
-  return pick_rmax(n_rows, kWave) <= 2 ? mx : mx * 2 / 3;
+  return pick_rmax(n_rows, kWave) <= 2 ? mx * 3 / 2 : mx * 3 / 4;
 }
 
 // a wavefront per chain runs the canonical tree (or, strict order, the serial sum) whenever the pedigree is LDS-resident

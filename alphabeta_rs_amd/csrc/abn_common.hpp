@@ -365,6 +365,7 @@ __device__ __forceinline__ void build_power_table_mx(double al, double be, int T
   double A[NH], B[NH];
   double* dst[NH];
   int step[NH];
+  (void)dump;
 #pragma unroll
   for (int h = 0; h < NH; ++h) {
     const int c = blk + 4 * h;                // the chain this lane's block works for
@@ -387,11 +388,12 @@ __device__ __forceinline__ void build_power_table_mx(double al, double be, int T
     A[h] = in3 ? gyx : 0.0;
     // B = (G^1)^T: element G[x][y] = A of the lane with x and y exchanged (same block)
     B[h] = lane_fetch(A[h], y + 4 * blk + 16 * x);
-    // lanes outside the 3x3 block (or of an unused block) store too — always to `dump`, a slot of the caller's that
-    // nobody reads before it is rewritten: no store predicate in the loop
+    // lanes outside the 3x3 block (or of an unused block) store too — to the padding element [9] of the same entry of the
+    // first chain's table, which nobody reads: no store predicate in the loop and ONE pitch for all lanes, so the
+    // stores of a trip differ by an immediate offset
     const bool st = in3 && (c < NG);
-    dst[h] = st ? lds0 + (size_t)c * chain_stride + 3 * x + y : dump;
-    step[h] = st ? kPw : 0;
+    dst[h] = st ? lds0 + (size_t)c * chain_stride + 3 * x + y : lds0 + 9;
+    step[h] = kPw;
     dst[h][0] = (x == y) ? 1.0 : 0.0;         // identity, :21-24
     dst[h] += step[h];
     if (T >= 1) dst[h][0] = B[h];             // matrix.clone(), :25
@@ -399,22 +401,39 @@ __device__ __forceinline__ void build_power_table_mx(double al, double be, int T
   // :27-29.  Power n is stored while the instruction for power n+1 runs (the store needs the finished result
   // anyway; issued right behind the dependent MFMA it hides in its 48-cycle shadow).
   // (build_power_table_mx_pre below repeats this loop for one chain.)
-  if (T >= 2) {
+  if (T >= 2) {   // two powers per trip, alternating registers: see build_power_table_mx_pre
+    double Bn[NH], Bm[NH];
 #pragma unroll
-    for (int h = 0; h < NH; ++h) B[h] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[h], B[h], 0.0, 0, 0, 0);
-    for (int n = 3; n <= T; ++n) {
+    for (int h = 0; h < NH; ++h) Bn[h] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[h], B[h], 0.0, 0, 0, 0);
+    int n = 3;
+    for (; n + 1 <= T; n += 2) {
 #pragma unroll
       for (int h = 0; h < NH; ++h) {
-        const double nxt = __builtin_amdgcn_mfma_f64_4x4x4f64(A[h], B[h], 0.0, 0, 0, 0);
+        Bm[h] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[h], Bn[h], 0.0, 0, 0, 0);
         dst[h] += step[h];
-        dst[h][0] = B[h];
-        B[h] = nxt;
+        dst[h][0] = Bn[h];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (or hipcc pairs these stores with the next ones, which wait for power n)
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        Bn[h] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[h], Bm[h], 0.0, 0, 0, 0);
+        dst[h] += step[h];
+        dst[h][0] = Bm[h];
+      }
+    }
+    if (n <= T) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h) {
+        Bm[h] = __builtin_amdgcn_mfma_f64_4x4x4f64(A[h], Bn[h], 0.0, 0, 0, 0);
+        dst[h] += step[h];
+        dst[h][0] = Bn[h];
+        Bn[h] = Bm[h];
       }
     }
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       dst[h] += step[h];
-      dst[h][0] = B[h];
+      dst[h][0] = Bn[h];
     }
   }
 }
@@ -424,21 +443,36 @@ __device__ __forceinline__ void build_power_table_mx(double al, double be, int T
 __device__ __forceinline__ void build_power_table_mx_pre(double A, double B, int T, double* pw, double* dump, int lane) {
   const int x = lane & 3, blk = (lane >> 2) & 3, y = lane >> 4;
   const bool st = (x < 3) && (y < 3) && (blk == 0);
-  double* dst = st ? pw + 3 * x + y : dump;
-  const int step = st ? kPw : 0;
+  double* dst = st ? pw + 3 * x + y : pw + 9;   // the other lanes: the entry's padding element (never read)
+  constexpr int step = kPw;
+  (void)dump;
   dst[0] = (x == y) ? 1.0 : 0.0;              // identity, :21-24
   dst += step;
   if (T >= 1) dst[0] = B;                     // matrix.clone(), :25
   if (T >= 2) {                               // :27-29
-    B = __builtin_amdgcn_mfma_f64_4x4x4f64(A, B, 0.0, 0, 0, 0);
-    for (int n = 3; n <= T; ++n) {
-      const double nxt = __builtin_amdgcn_mfma_f64_4x4x4f64(A, B, 0.0, 0, 0, 0);
+    // Two powers per trip with alternating registers: the instruction for power n is issued as soon as power n - 1 is there
+    // and the store of power n - 1 follows in its shadow.  (One register and one power per trip made hipcc put the store
+    // first — it has to read the register the instruction overwrites — and with the loop's branch a power cost 86 cycles
+    // instead of the instruction's 48: in-kernel stamps, 31 powers of the 351-row pedigree 2 680 cycles.)
+    double Bn = __builtin_amdgcn_mfma_f64_4x4x4f64(A, B, 0.0, 0, 0, 0);   // power 2
+    int n = 3;
+    for (; n + 1 <= T; n += 2) {
+      const double Bm = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bn, 0.0, 0, 0, 0);  // power n
       dst += step;
-      dst[0] = B;
-      B = nxt;
+      dst[0] = Bn;                                                                 // power n - 1
+      __builtin_amdgcn_sched_barrier(0);   // (or hipcc pairs this store with the next one, which waits for power n)
+      Bn = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bm, 0.0, 0, 0, 0);               // power n + 1
+      dst += step;
+      dst[0] = Bm;
+    }
+    if (n <= T) {
+      const double Bm = __builtin_amdgcn_mfma_f64_4x4x4f64(A, Bn, 0.0, 0, 0, 0);
+      dst += step;
+      dst[0] = Bn;
+      Bn = Bm;
     }
     dst += step;
-    dst[0] = B;
+    dst[0] = Bn;
   }
 }
 

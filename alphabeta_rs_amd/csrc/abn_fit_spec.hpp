@@ -143,7 +143,7 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 4 : 3) void abn_fit_spec_ker
   const int preA_idx = mx_in ? 3 * mx_y + mx_x : 10, preB_idx = mx_in ? 3 * mx_x + mx_y : 10;  // [10] holds 0.0
   // one evaluation of the candidate (al, be, wt, ic) — every lane holds all four; `pre`: preA / preB / prePen are this
   // candidate's (then al and be are not looked at)
-  auto eval = [&](double al, double be, double wt, double ic, bool pre) -> double {
+  auto eval = [&](double al, double be, double wt, double ic, bool pre) __attribute__((always_inline)) -> double {
     ABN_STAMP(6);  // control flow + candidate fetch since the exchange
     const double p_mm = wconst[1];
     const double sv0 = wconst[0], sv1 = wt * p_mm, sv2 = (1.0 - wt) * p_mm;
@@ -232,15 +232,15 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 4 : 3) void abn_fit_spec_ker
   if (!keeper) {
     int phase = 0, cb = 0, par = 0;
     double wt = 0.0, ic = 0.0, al = 0.0, be = 0.0;
-    auto put = [&](double f) {
+    auto put = [&](double f) __attribute__((always_inline)) {
       if (gl == 0) xch[4 * phase + wv] = f;
       __syncthreads();
       phase ^= 1;
     };
-    auto eval_point = [&](const double* x) { return eval(x[0], x[1], x[2], x[3], false); };
+    auto eval_point = [&](const double* x) __attribute__((always_inline)) { return eval(x[0], x[1], x[2], x[3], false); };
     // the candidate of outcome slot o for this wavefront: weight and intercept (every lane reads the same addresses), the
     // prepared inputs; al / be only where the matrix instruction is compiled out
-    auto fetch = [&](int o) {
+    auto fetch = [&](int o) __attribute__((always_inline)) {
       const double* t = tab + par * kSpecTabDoubles + o * 12 + 4 * wv;
       const double* g = gtab + par * kSpecPreDoubles + (o * 3 + wv) * 12;
       wt = t[2];
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 4 : 3) void abn_fit_spec_ker
         be = t[1];
       }
     };
-    auto pickup = [&]() -> bool {
+    auto pickup = [&]() __attribute__((always_inline)) -> bool {
       __syncthreads();
       const bool d = ctl[8 * cb + 5] != 0.0;
       if (!d) fetch(0);
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 4 : 3) void abn_fit_spec_ker
   int iter = 0;
   // IterState::update() + terminate_internal(): -1 = go on, else the ABN_FIT_* status.  `improved`: the best
   // vertex is the new best_param
-  auto ctl_begin = [&](bool count_iter, bool& improved) -> int {
+  auto ctl_begin = [&](bool count_iter, bool& improved) __attribute__((always_inline)) -> int {
     const double c_best = c[0];
     improved = c_best < best_cost || (__builtin_isinf(c_best) && __builtin_isinf(best_cost) &&
                                       (__builtin_signbit(c_best) == __builtin_signbit(best_cost)));
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 4 : 3) void abn_fit_spec_ker
   const int o_rank = oq < 4 ? oq : (oq == 4 ? 0 : oq - 5);
   // generation matrix and penalty term of the three candidates (r_, e_, c_: this lane's dimension) of outcome slot `oq` —
   // lane (quad, dimension t < 3) works for candidate t; same functions as an evaluation would call, so the same bits
-  auto emit_pre = [&](double r_, double e_, double c_, int parity) {
+  auto emit_pre = [&](double r_, double e_, double c_, int parity) __attribute__((always_inline)) {
     const double ar = dpp_mov<kDppQuadBcast0>(r_), br = dpp_mov<kDppQuadBcast1>(r_);
     const double ae = dpp_mov<kDppQuadBcast0>(e_), be = dpp_mov<kDppQuadBcast1>(e_);
     const double ac = dpp_mov<kDppQuadBcast0>(c_), bc = dpp_mov<kDppQuadBcast1>(c_);
@@ -390,11 +390,11 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 4 : 3) void abn_fit_spec_ker
       g[10] = 0.0;
     }
   };
-  auto ctl_write = [&](int status_now) {
+  auto ctl_write = [&](int status_now) __attribute__((always_inline)) {
     if (gl < 5) ctl[8 * cb + gl] = gl == 0 ? c[0] : (gl == 1 ? c[1] : (gl == 2 ? c[2] : (gl == 3 ? c[3] : c[4])));
     if (gl == 5) ctl[8 * cb + 5] = status_now >= 0 ? 1.0 : 0.0;
   };
-  auto take = [&](double& f0, double& f1, double& f2) {
+  auto take = [&](double& f0, double& f1, double& f2) __attribute__((always_inline)) {
     const double* buf = xch + 4 * phase;
     __syncthreads();
     f0 = buf[0];
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 4 : 3) void abn_fit_spec_ker
   bool improved;
   int status = -1;
   double f1, f2;
-  auto publish = [&]() -> bool {
+  auto publish = [&]() __attribute__((always_inline)) -> bool {
     ctl_write(status);
     if (status < 0) {  // centroid (p0 + p1 + p2 + p3) * (1/4), x0 + (x0 - xw) * alpha, x0 + (xr - x0) * gamma, x0 + (xw - x0) * rho
       double acc = vx[0];

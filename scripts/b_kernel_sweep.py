@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Measurement aid (GPU box, knobs build: ABNEUTRAL_HIP_LIB=build/variants/libabn_knobs.so): phase-B time of a pedigree
+"""Measurement aid (GPU box, knobs build: ABNEUTRAL_HIP_LIB=build/libabn_knobs.so): phase-B time of a pedigree
 against the number of bootstraps for each kernel — speculative (four wavefronts per chain), one wavefront per chain,
 packed — to place the thresholds of abn_api.hip.  usage: b_kernel_sweep.py <c2|c3|g351|sparse>"""
 import json, os, subprocess, sys
@@ -29,10 +29,10 @@ for _ in range(5):
 print(json.dumps({"ms": min(ms)}))
 ''' % str(ROOT)
 which = sys.argv[1] if len(sys.argv) > 1 else "c2"
-for B in (250, 500, 1000, 2000, 4000):
+for B in (500, 1000, 1500, 2000, 3000, 4000):
     row = {}
     for k in ("spec", "wide", "packed"):
-        env = dict(os.environ, ABN_PHASE_B_KERNEL=k, ABNEUTRAL_HIP_LIB=str(ROOT / "build/variants/libabn_knobs.so"))
+        env = dict(os.environ, ABN_PHASE_B_KERNEL=k, ABNEUTRAL_HIP_LIB=str(ROOT / "build/libabn_knobs.so"))
         r = subprocess.run([sys.executable, "-c", code, which, str(B)], capture_output=True, text=True, env=env)
         try:
             row[k] = round(json.loads(r.stdout.strip().splitlines()[-1])["ms"], 3)

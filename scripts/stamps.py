@@ -19,6 +19,10 @@ L.abn_plan_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
 from alphabeta_rs_amd import synthetic
 ctx = A.Context(0)
 ped, p0 = synthetic.c3_pedigree()
+if len(sys.argv) > 1 and sys.argv[1] == "g351":   # the reference's golden pedigree (351 rows, T = 32, K = 10)
+    rows = [[float(t) for t in ln.replace("\t", " ").split()] for ln in
+            (ROOT / "tests" / "golden" / "pedigree.txt").read_text().splitlines()[1:] if ln.strip()]
+    ped, p0 = np.asarray(rows), 0.75
 names = ["P1 bcast+genmatrix+puu", "P2 power table", "P3 triples", "P4 rows", "P5 reduce", "-", "P6 NM update", "evals"]
 for lanes in (16, 64):
     plan = A.Plan(ctx, ped[:, :3], 1, 1, 0, options=A.default_options(lanes_per_chain=lanes))

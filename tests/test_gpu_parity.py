@@ -948,6 +948,8 @@ def test_kernel_choice_follows_the_launch_size(abn, gpu_ctx):
     assert k["starts"] == ("speculative", 64) and k["boot"] == ("persistent", 16)
     k = kernels(ped[:, :3], ped[:, 3], p0, 1, 10, 1000)         # few bootstraps: latency-bound like the starts
     assert k["boot"] == ("speculative", 64)
+    k = kernels(ped[:, :3], ped[:, 3], p0, 1, 10, 1500)         # ... up to 1.5 x what that kernel keeps resident (6 per CU)
+    assert k["boot"] == ("speculative", 64)
     k = kernels(ped[:, :3], ped[:, 3], p0, 1, 10, 2500)         # a wavefront per chain still beats packing
     assert k["boot"] == ("resident", 64)
     k = kernels(ped[:, :3], ped[:, 3], p0, 1, 10, 6000)         # packed, fits the GPU: the plain launch

@@ -70,3 +70,21 @@ def test_no_trap_in_any_fit_kernel(device_isa):
     for needle in ("abn_fit_kernel", "abn_fit_spec_kernel", "abn_fit_refill_kernel"):
         for name, body in functions(device_isa, needle).items():
             assert not any(ln.startswith("s_trap") for ln in body), name
+
+
+def test_no_device_function_is_called_and_nothing_spills_in_the_speculative_kernel(device_isa):
+    """Round 4: after a restructuring hipcc stopped inlining the evaluation lambda of abn_fit_spec_kernel<8, ...> — the kernel
+    then CALLED it (s_swappc_b64), every LDS access of the callee became a flat load, and the 351-row golden pedigree lost
+    30 % without any test noticing (the results are the same).  No fit kernel may contain a call, no lambda may survive as
+    a function of its own, and the speculative kernel — whose four-workgroups-per-CU residency rests on it — has no scratch."""
+    assert not re.search(r"^_ZZN3abn\w*:", device_isa, re.M), "a device lambda was emitted as a function (not inlined)"
+    for needle in ("abn_fit_kernel", "abn_fit_spec_kernel", "abn_fit_refill_kernel", "abn_cost_kernel"):
+        for name, body in functions(device_isa, needle).items():
+            assert not any(ln.startswith("s_swappc_b64") for ln in body), name
+    for m in re.finditer(r"^\s*\.amdhsa_kernel (_ZN3abn19abn_fit_spec_kernel\w+)\n(.*?)\.end_amdhsa_kernel", device_isa, re.S | re.M):
+        priv = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", m.group(2))
+        vgpr = re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2))
+        assert priv and int(priv.group(1)) == 0, (m.group(1), priv and priv.group(1))
+        assert vgpr and int(vgpr.group(1)) <= 168, (m.group(1), vgpr and vgpr.group(1))
+        if "ILi1E" in m.group(1) or "ILi2E" in m.group(1):     # up to two rows per lane: four workgroups per CU
+            assert int(vgpr.group(1)) <= 128, (m.group(1), vgpr.group(1))
