@@ -329,15 +329,21 @@ static bool fit_streams(int n, int chain_stride, int lanes, int strict) {
 
 // Speculative kernel (phase A; three evaluation wavefronts + a bookkeeping wavefront per chain): resident mode
 // with one wavefront per candidate only.
-// Chains up to which the speculative kernel is used: 1.5 x what the GPU holds at once for pedigrees of up to two rows per
-// lane (four workgroups per CU -> 1536 chains on the MI355X), what it holds beyond (three per CU -> 768).  Phase-B time,
-// speculative / one wavefront per chain / packed (scripts/b_kernel_sweep.py, profiles/r04_b_kernel_sweep.txt): C3 topology
-// 1000 chains 0.76 / 1.03 / 1.60 ms, 1500: 1.04 / 1.15 / 1.16, 2000: 1.28 / 1.31 / 1.31, 3000: 1.70 / 1.49 / 1.48; the bundled
-// 6-row pedigree 1500: 1.44 / 1.95 / 1.95, 3000: 1.95 / 2.43 / 2.26; the 351-row golden pedigree 500: 1.21 / 1.95 / 1.95,
-// 1000: 2.14 / 1.97 / 1.96.  Phase A (scripts/phase_a_sweep.py, C3 topology): 1000 chains 1.94 ms against 3.18 ms.
-static long long spec_max_chains(const abn_ctx* c, int n_rows) {
-  const long long mx = kPhaseASpecPerCu * c->cus;
-  return pick_rmax(n_rows, kWave) <= 2 ? mx * 3 / 2 : mx * 3 / 4;
+// Chains up to which the speculative kernel is used.  What the GPU holds at once: four workgroups per CU for pedigrees of up
+// to two rows per lane (1024 chains on the MI355X), three beyond (768); workgroups beyond that start as earlier ones end.
+// Phase B (bootstrap chains: similar lengths) up to 1.5 x / 1 x of that; phase A (start chains from random points: lengths
+// differ several-fold, so the queue behind the resident chains drains into slots that free early) up to 4 x / 2.7 x.
+// Speculative / one wavefront per chain / packed, ms (scripts/b_kernel_sweep.py, scripts/a_kernel_sweep.py,
+// profiles/r04_b_kernel_sweep.txt, r04_a_kernel_sweep.txt):
+//   phase B, C3 topology: 1000 chains 0.76 / 1.03 / 1.60, 1500: 1.04 / 1.15 / 1.16, 2000: 1.28 / 1.31 / 1.31, 3000: 1.70 / 1.49 / 1.48;
+//            6-row pedigree 1500: 1.44 / 1.95 / 1.95, 3000: 1.95 / 2.43 / 2.26; 351-row pedigree 500: 1.21 / 1.95 / 1.95, 1000: 2.14 / 1.97 / 1.96
+//   phase A, C3 topology: 1000 chains 1.89 / 2.94 / 4.80, 2000: 2.71 / 3.31 / 4.94, 3000: 3.45 / 3.67 / 5.06, 4000: 4.21 / 4.40 / 6.13,
+//            5000: 5.10 / 5.16 / 6.46, 6000: 6.15 / 5.75 / 6.43; 351-row pedigree 1000: 3.25 / 3.77 / 3.78, 2000: 6.11 / 6.43 / 6.31, 3000: 6.30 / 6.55 / 6.54
+static long long spec_max_chains(const abn_ctx* c, int n_rows, int phase) {
+  const long long mx = kPhaseASpecPerCu * c->cus;   // 1024
+  const bool small = pick_rmax(n_rows, kWave) <= 2;
+  if (phase == 0) return small ? mx * 4 : mx * 2;
+  return small ? mx * 3 / 2 : mx * 3 / 4;
 }
 
 // a wavefront per chain runs the canonical tree (or, strict order, the serial sum) whenever the pedigree is LDS-resident
@@ -1108,7 +1114,7 @@ static int enqueue_phase_a(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   // few chains: latency-bound -> three wavefronts per chain evaluate reflection / expansion / contraction at once,
   // a fourth keeps the simplex and prepares the next candidates meanwhile (abn_fit_spec_kernel)
   bool spec = p->lanes_a == 64 && p->opt.lanes_per_chain == 0 &&
-              (long long)p->W * p->S <= spec_max_chains(c, p->N) && spec_applicable(a);
+              (long long)p->W * p->S <= spec_max_chains(c, p->N, 0) && spec_applicable(a);
   int lanes_a = p->lanes_a;
 #ifdef ABN_MEASUREMENT_KNOBS  // ABN_PHASE_A_KERNEL = spec | wide | packed  (scripts/phase_a_sweep.py)
   if (const char* e = getenv("ABN_PHASE_A_KERNEL")) {
@@ -1225,7 +1231,7 @@ static int enqueue_phase_b(abn_plan* p, int w0, int wn, hipStream_t st, bool tim
   }
   // few bootstraps: latency-bound like phase A -> the speculative kernel (four wavefronts per chain)
   bool spec = a.dmode == 1 && p->opt.lanes_per_chain == 0 &&
-              (long long)p->W * p->B <= spec_max_chains(c, p->N) && spec_applicable(a);
+              (long long)p->W * p->B <= spec_max_chains(c, p->N, 1) && spec_applicable(a);
   int lanes_b = p->lanes;
   // ... and up to 192 chains per packed lane (3072 for the 16-lane kernels) a wavefront per chain still beats packing
   // several chains into one (scripts/b_kernel_sweep.py, C3 topology: 2000 bootstraps 1.36 ms against 1.74 ms packed and

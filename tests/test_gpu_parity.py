@@ -956,6 +956,10 @@ def test_kernel_choice_follows_the_launch_size(abn, gpu_ctx):
     assert k["boot"] == ("resident", 16)
     k = kernels(ped[:, :3], ped[:, 3], p0, 25, 10, 1000)        # a multi-window shard: persistent with time slicing
     assert k["starts"] == ("speculative", 64) and k["boot"] == ("persistent", 16)
+    k = kernels(ped[:, :3], ped[:, 3], p0, 200, 10, 2)          # BASELINE C4's 2000 start chains: still speculative (phase A: up to 16 per CU)
+    assert k["starts"] == ("speculative", 64)
+    k = kernels(ped[:, :3], ped[:, 3], p0, 500, 10, 2)          # 5000 start chains: a wavefront per chain
+    assert k["starts"] == ("resident", 64)
     k = kernels(ped[:, :3], ped[:, 3], p0, 1, 10, 10000, strict_order=1)   # strict order: speculative or plain launches
     assert k["starts"] == ("speculative", 64) and k["boot"] == ("resident", 16)
     k = kernels(deep[:, :3], deep[:, 3], dp0, 1, 2, 4)          # 3240 rows: streamed
