@@ -1361,7 +1361,9 @@ static int verify_persistent(abn_plan* p) {
     if (sl[4 * ph] != 0 || (long long)sl[4 * ph + 1] != p->persist_expected[ph])
       return set_err(c, ABN_ERR_HIP, std::string("persistent fit launch of phase ") + (ph ? "B" : "A") + " finished " +
                                          std::to_string(sl[4 * ph + 1]) + " of " + std::to_string(p->persist_expected[ph]) +
-                                         " chains (error word " + std::to_string(sl[4 * ph]) + "): results are incomplete");
+                                         " chains (error word " + std::to_string(sl[4 * ph]) + ", " + std::to_string(sl[4 * ph + 2]) +
+                                         " handed to the speculative kernel, list length " + std::to_string(sl[4 * ph + 3]) +
+                                         "): results are incomplete");
   }
   return ABN_OK;
 }

@@ -39,8 +39,10 @@ __global__ __launch_bounds__(kWave, TWOPASS ? 2 : (RMAX == 0 ? kStreamWaves : 3)
   bool valid = slot < total;
   if constexpr (TWOPASS) {
     if (a.resume) {  // second pass: the compacted list of suspended chains
-      valid = slot < (long long)*a.susp_count;
-      chain_raw = valid ? (long long)a.susp_list[slot] : 0;
+      // count and entry past the caches (agent scope), as abn_fit_spec_kernel's resume launch reads them: written by
+      // device-scope atomics of the first pass on every XCD
+      valid = slot < (long long)__hip_atomic_load(a.susp_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      chain_raw = valid ? (long long)__hip_atomic_load(a.susp_list + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     }
   }
   const long long chain = valid ? chain_raw : 0;

@@ -489,8 +489,23 @@ __global__ __launch_bounds__(kWave, ABN_REFILL_MIN_WAVES) void abn_fit_refill_ke
         if (nxt == 0xffffffffu && a.quantum > 0) {
           // oldest parked chain, if any: claim a credit first (given back if there was none), then a ticket — a
           // ticket is only ever taken against a published entry, so none is lost and nobody loops
+          // A failed claim leaves the counter one too low until it is given back, so a claim that runs into another
+          // group's failed one can fail although a chain IS parked (the parking group's own claim, for one) — and if both
+          // then went idle with no later finisher in their FIFO shard, the chain stayed parked for good: seen in round 4 as
+          // "finished 13999 of 14000 chains" in 1 run of 15 of a launch whose wavefronts wind down together (tail
+          // hand-over).  So whoever gives a credit back looks again: the last one to do so sees the true count.
           int* avail = reinterpret_cast<int*>(pht) + kParkAvail;
-          if (atomicSub(avail, 1) > 0) {
+          bool claimed = false;
+          for (int tries = 0; tries < 1024 && !claimed; ++tries) {
+            if (atomicSub(avail, 1) > 0) {
+              claimed = true;
+            } else {
+              atomicAdd(avail, 1);
+              if (__hip_atomic_load(avail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) break;
+              __builtin_amdgcn_s_sleep(1);
+            }
+          }
+          if (claimed) {
             const unsigned h = atomicAdd(pht + kParkHead, 1u);
             // entries are published in any order: the one of this ticket may be a few instructions away (its writer
             // is a running wavefront past its reservation).  Bounded all the same: a lost entry must neither hang the
@@ -508,8 +523,6 @@ __global__ __launch_bounds__(kWave, ABN_REFILL_MIN_WAVES) void abn_fit_refill_ke
             } else if (a.slice_status) {
               atomicOr(a.slice_status, kSliceErrLostEntry);
             }
-          } else {
-            atomicAdd(avail, 1);
           }
         }
       }

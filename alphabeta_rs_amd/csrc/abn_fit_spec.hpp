@@ -54,9 +54,15 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 4 : 3) void abn_fit_spec_ker
   const bool keeper = wv == 3;
   long long chain = blockIdx.x;         // grid = W*C exactly ...
   if constexpr (RESUME) {               // ... or the tail of a persistent launch: slot b takes a parked chain up again
-    if ((int)blockIdx.x >= *a.susp_count) return;   // (uniform in the workgroup, before any barrier)
-    chain = a.susp_list[blockIdx.x];
+    // The list, its length and the parked states were written by the wavefronts of the persistent launch on every XCD
+    // (device-scope atomics on the counter, write-through stores for the states); a kernel boundary lies in between, and
+    // they are read past the caches all the same, like the persistent kernel's own resume path reads them.
+    if ((int)blockIdx.x >= __hip_atomic_load(a.susp_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;   // uniform in the workgroup, before any barrier
+    chain = __hip_atomic_load(a.susp_list + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  [[maybe_unused]] auto parked = [&](int i) __attribute__((always_inline)) {   // RESUME: word i of the chain's parked state
+    return __hip_atomic_load(a.state + (size_t)chain * 32 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   const int w = (int)(chain / a.C);
   const int N = a.N, K = a.K, TP = a.TP;
 
@@ -101,9 +107,8 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 4 : 3) void abn_fit_spec_ker
     // start simplex (starts: given; bootstraps: [params, vary() x4], src/boot_model.rs:69-75), handed to the
     // evaluation wavefronts through the (still unused) candidate table
     if constexpr (RESUME) {   // the sorted simplex as abn_fit_refill_kernel parked it at an iteration boundary
-      const double* sp = a.state + (size_t)chain * 32;
 #pragma unroll
-      for (int k = 0; k < 5; ++k) vx[k] = sp[4 * k + dim];
+      for (int k = 0; k < 5; ++k) vx[k] = parked(4 * k + dim);
     } else if (a.smode == 0) {
       const double* s0 = a.simplex0 + (size_t)chain * 20;
 #pragma unroll
@@ -432,15 +437,14 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 4 : 3) void abn_fit_spec_ker
   if constexpr (RESUME) {
     // a chain parked by the persistent kernel at an iteration boundary (IterState::update and the termination test of that
     // iteration are behind it: status < 0): costs, best vertex and counters as stored, then straight to the candidates
-    const double* sp = a.state + (size_t)chain * 32;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) c[k] = sp[20 + k];
-    bx = sp[25 + dim];
-    best_cost = sp[29];
-    const long long ie = __double_as_longlong(sp[30]);
+    for (int k = 0; k < 5; ++k) c[k] = parked(20 + k);
+    bx = parked(25 + dim);
+    best_cost = parked(29);
+    const long long ie = __double_as_longlong(parked(30));
     iter = (int)(ie & 0xffffffffll);
     evals = (int)(ie >> 32);
-    have_best = __double_as_longlong(sp[31]) != 0;
+    have_best = __double_as_longlong(parked(31)) != 0;
   } else {
     // Solver::init: the five start costs in input order (3 + 2), stable sort, first termination check
     take(c[0], c[1], c[2]);
@@ -564,7 +568,11 @@ __global__ __launch_bounds__(4 * kWave, RMAX <= 2 ? 4 : 3) void abn_fit_spec_ker
   const double b0 = dpp_mov<kDppQuadBcast0>(bx), b1 = dpp_mov<kDppQuadBcast1>(bx);
   if (gl < 4) a.best[(size_t)chain * 4 + gl] = bx;
   if (gl == 0) {
+#ifdef ABN_DIAG_RESUME_COUNT   // diagnosis only (scripts/repro_lost_chain.py): the resume launch counts in the upper half of the word
+    if constexpr (RESUME) atomicAdd(a.slice_status + 1, 0x10000u);
+#else
     if constexpr (RESUME) atomicAdd(a.slice_status + 1, 1u);  // the persistent launch's count of finished fits
+#endif
     FitInfoDev fo;
     fo.best_cost = best_cost;
     fo.iters = iter;
