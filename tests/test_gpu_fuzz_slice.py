@@ -7,6 +7,7 @@ offsets).  Bounded by cases and by time (about a minute together)."""
 import importlib.util
 from pathlib import Path
 
+import numpy as np
 import pytest
 
 FUZZ = Path(__file__).resolve().parent / "fuzz"
@@ -38,6 +39,7 @@ def test_fuzz_plan_slice(abn, gpu_ctx, oracle, capsys):
     assert int(out.split("fuzz_plan:")[1].split()[0]) >= 10, out
 
 
+@pytest.mark.gpu
 def test_tail_hand_over_loses_no_chain(abn, gpu_ctx, oracle):
     """Case 371 of `fuzz_plan.py 300 505` (round 4): 7 windows x 2000 short bootstrap chains (100 iterations at most, many of
     them shrinking) of a 40-row pedigree.  In 1 run of 15 the persistent launch ended with one chain still parked in a
