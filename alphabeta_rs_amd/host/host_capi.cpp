@@ -12,7 +12,7 @@ int abh_pedigree_build(const char* nodelist, const char* edgelist, double poster
     auto [ped, p0] = alphabeta::Pedigree::build(nodelist, edgelist, posterior_max_filter);
     const int n = (int)ped.nrows();
     if (n > cap) return -2;
-    std::memcpy(rows, ped.data.data(), sizeof(double) * 4 * (size_t)n);
+    if (n > 0) std::memcpy(rows, ped.data.data(), sizeof(double) * 4 * (size_t)n);  // an empty pedigree has no buffer
     *p0uu = p0;
     return n;
   } catch (const std::exception& e) {
