@@ -97,18 +97,21 @@ def _normalise(wf, cs, order=NEXT):
         idx = 0
 
 
-def explore(n_waves, ng, work, recheck=True, tail_cap=0, cap=64, limit=3_000_000, order=NEXT, count_stranded=False):
-    """work[c] = quanta chain c runs for.  -> dict of counts; raises Violation on a broken property."""
+def explore(n_waves, ng, work, recheck=True, tail_cap=0, cap=64, limit=3_000_000, order=NEXT, count_stranded=False,
+            shards=1):
+    """work[c] = quanta chain c runs for; wavefront w parks in and claims from FIFO shard w % shards (the kernel's
+    blockIdx & (kParkShards - 1)); queue, finished count and tail list are shared.  -> dict of counts; raises Violation on a
+    broken property."""
     total, base = len(work), n_waves * ng
     assert total >= base
     wf0 = [(P_TAILCHK, 0, False, False, tuple((w * ng + j, RUN, False, -1, -1, 0) for j in range(ng))) for w in range(n_waves)]
     cs0 = tuple(C_RUNNING if c < base else C_UNSTARTED for c in range(total))
     # shared words: queue, tail, head, avail, finished, the FIFO's entries, the tail list
-    start = (0, 0, 0, 0, 0, (-1,) * cap, (), tuple(work), cs0, tuple(wf0))
+    start = (0, (0,) * shards, (0,) * shards, (0,) * shards, 0, ((-1,) * cap,) * shards, (), tuple(work), cs0, tuple(wf0))
     seen, stack = {start}, [start]
     out = dict(states=0, terminals=0, stranded=0, tail_parks=0, fifo_parks=0, waits=0)
     while stack:
-        Q, T, H, A, FIN, pk, susp, wk, cs, wfs = stack.pop()
+        Q, Ts, Hs, As, FIN, pks, susp, wk, cs, wfs = stack.pop()
         out["states"] += 1
         if out["states"] > limit:
             raise RuntimeError("state limit")
@@ -123,8 +126,8 @@ def explore(n_waves, ng, work, recheck=True, tail_cap=0, cap=64, limit=3_000_000
             n_done, n_tail = cs.count(C_DONE), cs.count(C_TAIL)
             if FIN != n_done or sorted(susp) != [c for c in range(total) if cs[c] == C_TAIL] or FIN + len(susp) != total:
                 raise Violation(f"counters: finished {FIN} of {n_done}, tail list {susp} of {n_tail}")
-            if A != 0 or T != H:
-                raise Violation(f"left over: {A} credits, tail {T}, head {H}")
+            if any(As) or Ts != Hs:
+                raise Violation(f"left over: {As} credits, tails {Ts}, heads {Hs}")
             out["tail_parks"] = max(out["tail_parks"], n_tail)
             continue
         succ = []
@@ -132,10 +135,16 @@ def explore(n_waves, ng, work, recheck=True, tail_cap=0, cap=64, limit=3_000_000
             pc, idx, tail_mode, wave_fd, groups = wf
             if pc == P_EXIT:
                 continue
+            sh = w % shards
+            T, H, A, pk = Ts[sh], Hs[sh], As[sh], pks[sh]
+
+            def put(tup, v):
+                return tup[:sh] + (v,) + tup[sh + 1:]
 
             def emit(groups_, pc_=pc, idx_=idx, tm=tail_mode, Q=Q, T=T, H=H, A=A, FIN=FIN, pk=pk, susp=susp, wk=wk, cs=cs):
                 nwf, ncs = _normalise((pc_, idx_, tm, wave_fd, groups_), cs, order)
-                succ.append((Q, T, H, A, FIN, pk, susp, wk, ncs, wfs[:w] + (nwf,) + wfs[w + 1:]))
+                succ.append((Q, put(Ts, T), put(Hs, H), put(As, A), FIN, put(pks, pk), susp, wk, ncs,
+                             wfs[:w] + (nwf,) + wfs[w + 1:]))
 
             def with_group(i, g):
                 return groups[:i] + (g,) + groups[i + 1:]
@@ -162,7 +171,7 @@ def explore(n_waves, ng, work, recheck=True, tail_cap=0, cap=64, limit=3_000_000
                 nwk = wk[:chain] + (wk[chain] - 1,) + wk[chain + 1:]
                 if nwk[chain] == 0:
                     nst = FINISHED
-                elif (base + Q < total or A > 0) and T + base + ng < cap:
+                elif (base + Q < total or A > 0) and T + base // shards + ng < cap:
                     nst = PARK_FIFO
                 elif tail_mode:
                     nst = PARK_TAIL
@@ -197,7 +206,7 @@ def explore(n_waves, ng, work, recheck=True, tail_cap=0, cap=64, limit=3_000_000
                 else:
                     out["waits"] += 1
         if not succ:
-            raise Violation(f"deadlock: {[(wf[0], wf[1]) for wf in wfs]}, entries {pk[:T]}, head {H}, avail {A}")
+            raise Violation(f"deadlock: {[(wf[0], wf[1]) for wf in wfs]}, entries {pks}, heads {Hs}, credits {As}")
         for s in succ:
             if s not in seen:
                 seen.add(s)
@@ -221,6 +230,17 @@ def test_whole_protocol_loses_no_chain_and_never_deadlocks(n_waves, ng, work, ta
     assert out["fifo_parks"] > 0, out                       # the model does reach the FIFO
     if tail_cap:
         assert out["tail_parks"] > 0, out                   # ... and the tail list
+
+
+@pytest.mark.parametrize("n_waves,ng,work,tail_cap", [
+    (2, 1, (3, 2, 2, 1), 0),            # a shard each: a parked chain can only be taken up by its own wavefront
+    (3, 1, (2, 3, 2, 1), 0),            # two wavefronts share shard 0, the third has its own
+    (2, 2, (3, 2, 3, 2, 1), 2),
+    (3, 1, (3, 3, 2, 1), 3),
+])
+def test_two_fifo_shards_lose_no_chain_either(n_waves, ng, work, tail_cap):
+    out = explore(n_waves, ng, work, recheck=True, tail_cap=tail_cap, shards=2)
+    assert out["terminals"] > 0 and out["stranded"] == 0 and out["fifo_parks"] > 0, out
 
 
 def test_a_waiting_wavefront_is_a_reachable_state():
