@@ -210,6 +210,10 @@ def analyze(raw) -> np.ndarray:
     """src/analysis.rs:50-98 -> (4, 8): mean, sd, ci_lo, ci_hi x (alpha, beta, beta/alpha, weight,
     intercept, pr_mm, pr_um, pr_uu)."""
     raw = _f64(raw).reshape(-1, 7)
+    with np.errstate(all="ignore"):
+        bad = np.isnan(raw).any(axis=1) | np.isnan(raw[:, 1] / raw[:, 0])
+    if bad.any():   # abn_analyze sorts with `<`: NaN-free columns only (the reference panics before it gets here)
+        raise AbnError(5, f"bootstrap {int(np.flatnonzero(bad)[0])} has no finite fit: no analysis of this table")
     out = np.empty(32)
     rc = load_library().abn_analyze(_dp(raw), raw.shape[0], _dp(out))
     if rc:

@@ -213,6 +213,15 @@ struct RawAnalysis {  // src/analysis.rs:12 — n_boot x 7: alpha, beta, weight,
   std::vector<double> rows;
   size_t n_boot = 0;
   Analysis analyze() const {  // src/analysis.rs:50-98
+    // A bootstrap fit without a finite best vertex is a NaN row here (status ABN_FIT_NONFINITE); the reference never gets
+    // this far (best_param.unwrap() panics, src/boot_model.rs:86).  Quantiles of NaN have no order — abn_analyze sorts with
+    // `<` and requires NaN-free columns (include/abneutral.h) —, so the mirror refuses the table like the reference does.
+    for (size_t b = 0; b < n_boot; ++b) {
+      bool bad = std::isnan(rows[7 * b + 1] / rows[7 * b]);  // beta / alpha, src/analysis.rs:54
+      for (size_t k = 0; k < 7; ++k) bad = bad || std::isnan(rows[7 * b + k]);
+      if (bad)
+        throw Error(ABN_ERR_NO_FINITE_FIT, "bootstrap " + std::to_string(b) + " has no finite fit: no analysis of this table");
+    }
     double o[32];
     int rc = abn_analyze(rows.data(), (int64_t)n_boot, o);
     if (rc) throw Error(rc, "abn_analyze failed");

@@ -35,6 +35,19 @@ int abh_fmt_f64(double v, char* out, int cap) {
   std::memcpy(out, s.c_str(), s.size() + 1);
   return (int)s.size();
 }
+// RawAnalysis::analyze -> 0 and the mean of alpha, or -1 and the error text (a table with non-finite fits)
+int abh_analyze(const double* rows, long long n_boot, double* mean_alpha, char* err, int errcap) {
+  try {
+    alphabeta::RawAnalysis r;
+    r.n_boot = (size_t)n_boot;
+    r.rows.assign(rows, rows + 7 * n_boot);
+    *mean_alpha = r.analyze().alpha;
+    return 0;
+  } catch (const std::exception& e) {
+    if (err && errcap > 0) std::strncpy(err, e.what(), (size_t)errcap - 1), err[errcap - 1] = 0;
+    return -1;
+  }
+}
 int abh_write_npy(const char* path, const double* rows, long long n_boot) {
   alphabeta::RawAnalysis r;
   r.n_boot = (size_t)n_boot;

@@ -144,7 +144,12 @@ inline Output alphabeta_multiple(const WindowArgs& args, uint32_t max_gene_lengt
   }
   for (size_t i = 0; i < wins.size(); ++i) {
     if (!ok[i]) continue;
-    out.results.push_back(WindowResult{models[i], raws[i].analyze(), wins[i].region, 1.0 - wins[i].p0uu, wins[i].index});
+    try {
+      out.results.push_back(WindowResult{models[i], raws[i].analyze(), wins[i].region, 1.0 - wins[i].p0uu, wins[i].index});
+    } catch (const Error& e) {  // a bootstrap table with non-finite fits: this window fails, the others go on (:64-65)
+      std::printf("Error: Model failed: %s\n", e.what());
+      ok[i] = 0;
+    }
   }
   out.n_ok = out.results.size();
   // raw_analyses.push(Axis(2), ...) -> (iterations, 7, n_ok), C order (:49,68)

@@ -179,7 +179,10 @@ int abn_boot_model_run(abn_ctx* ctx, const abn_options* opts, const double* pedi
                        abn_fit_info* info);
 
 /* src/analysis.rs:50-98 on the host: out[32] = mean[8], sd[8], ci_lo[8], ci_hi[8] in the order
- * alpha, beta, beta/alpha, weight, intercept, pr_mm, pr_um, pr_uu (struct Analysis, :15-47). */
+ * alpha, beta, beta/alpha, weight, intercept, pr_mm, pr_um, pr_uu (struct Analysis, :15-47).
+ * Precondition: no NaN in raw nor in beta/alpha (rows of fits with status ABN_FIT_NONFINITE): the quantiles sort with `<`
+ * (the reference converts to n64, which rejects NaN, :57-58).  The host mirrors (RawAnalysis::analyze, the Python
+ * analyze()) check it and refuse such a table with ABN_ERR_NO_FINITE_FIT. */
 int abn_analyze(const double* raw, int64_t n_boot, double* out32);
 
 /* ------------------------------------------------------------------ pedigree construction

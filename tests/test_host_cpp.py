@@ -79,3 +79,25 @@ def test_cli_help_and_argument_errors():
     assert r.returncode == 0 and "--posterior-max-filter" in r.stdout and "--iterations" in r.stdout
     r = subprocess.run([cli, "-n", "/nonexistent/nodes.txt"], capture_output=True, text=True, cwd=str(GOLDEN))
     assert r.returncode == 2 and "valid file path" in r.stderr
+
+
+def test_analysis_refuses_a_table_with_non_finite_fits(hostlib, abn):
+    # a bootstrap without a finite best vertex is a NaN row; the reference panics before its analysis
+    # (src/boot_model.rs:86 best_param.unwrap()); quantiles of NaN have no order, so both mirrors refuse the table
+    hostlib.abh_analyze.argtypes = [C.POINTER(C.c_double), C.c_longlong, C.POINTER(C.c_double), C.c_char_p, C.c_int]
+    rng = np.random.default_rng(5)
+    raw = np.abs(rng.normal(1.0, 0.2, size=(40, 7)))
+    mean, err = C.c_double(), C.create_string_buffer(256)
+    assert hostlib.abh_analyze(raw.ctypes.data_as(C.POINTER(C.c_double)), 40, C.byref(mean), err, 256) == 0
+    assert mean.value == abn.analyze(raw)[0, 0]
+    for r, c, v in ((17, 2, np.nan), (0, 0, np.nan), (39, 6, np.nan), (5, (0, 1), 0.0), (7, (0, 1), np.inf)):
+        bad = raw.copy()
+        bad[r, c] = v                      # (0, 0) / (inf, inf): beta / alpha is NaN though the row is not
+        assert hostlib.abh_analyze(bad.ctypes.data_as(C.POINTER(C.c_double)), 40, C.byref(mean), err, 256) == -1
+        assert f"bootstrap {r} has no finite fit".encode() in err.value
+        with pytest.raises(abn.AbnError, match=f"ABN_ERR_NO_FINITE_FIT: bootstrap {r} "):
+            abn.analyze(bad)
+    inf = raw.copy()
+    inf[3, 2] = np.inf                     # infinities do have an order
+    assert hostlib.abh_analyze(inf.ctypes.data_as(C.POINTER(C.c_double)), 40, C.byref(mean), err, 256) == 0
+    assert np.isinf(abn.analyze(inf)[0, 3])

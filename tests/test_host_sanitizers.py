@@ -53,6 +53,12 @@ r7 = np.arange(21.0)
 L.abh_write_npy(os.path.join(work, "raw.npy").encode(), r7.ctypes.data_as(C.POINTER(C.c_double)), 3)
 assert np.load(os.path.join(work, "raw.npy")).size == 21
 L.abh_write_npy(os.path.join(work, "raw0.npy").encode(), r7.ctypes.data_as(C.POINTER(C.c_double)), 0)
+L.abh_analyze.argtypes = [C.POINTER(C.c_double), C.c_longlong, C.POINTER(C.c_double), C.c_char_p, C.c_int]
+tab = np.abs(np.random.default_rng(3).normal(1.0, 0.2, size=(64, 7))); m = C.c_double(); e = C.create_string_buffer(256)
+assert L.abh_analyze(tab.ctypes.data_as(C.POINTER(C.c_double)), 64, C.byref(m), e, 256) == 0
+assert L.abh_analyze(tab.ctypes.data_as(C.POINTER(C.c_double)), 1, C.byref(m), e, 256) == 0     # one row: sd is NaN, no overrun
+tab[9, 4] = np.nan
+assert L.abh_analyze(tab.ctypes.data_as(C.POINTER(C.c_double)), 64, C.byref(m), e, 256) == -1 and b"bootstrap 9" in e.value
 
 # (b) seeded corruptions of the fixture's files
 rng = random.Random(20261005)
